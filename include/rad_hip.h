@@ -1,0 +1,191 @@
+/*
+ * rad_hip.h — C ABI of librad_hip.so: the MI355X (gfx950) implementation of
+ * RAD's HNSW neighbor-expansion hot path.
+ *
+ * Host code (the Python files of rad_amd, or any other FFI) binds exactly these symbols; no
+ * torch / C++ types cross the boundary.  The reference (keiserlab/rad) has no
+ * FFI of its own for this path: it calls the pybind11 object `usearch.index.Index`
+ * (un-vendored fork, .gitmodules:1-3).  Each entry point below names the
+ * reference call it replaces (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, negative = RADHIP_E_*; a thread-local
+ *     message is readable through radhip_last_error().
+ *   - the caller owns every buffer it passes; the library copies what it keeps.
+ *   - no Python callbacks, no global state besides the per-process HIP context
+ *     that is created lazily by the first call that needs the device (so an
+ *     index object can be created in a parent and used in a forked child, as
+ *     rad/hnsw_service.py:129-134 does, provided the parent made no device call).
+ *   - there is NO CPU fallback: device entry points fail with RADHIP_E_NO_DEVICE
+ *     when no gfx950 device is visible.
+ *   - fingerprints are packed bits, ceil(ndim/8) bytes per row, any bit order
+ *     (np.packbits output, README.md:61); ndim <= 2048.
+ *   - "slot" is the 0-based insertion index of a node (RAD's node_id); slots
+ *     must be < 1e9 for the RAD traversal (its queue key packs the decimal
+ *     member-string order of rad/priority_queue.py:42 into 30+4 bits).
+ */
+#ifndef RAD_HIP_H
+#define RAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RADHIP_ABI_VERSION 1
+#define RADHIP_NO_SLOT 0xFFFFFFFFu
+
+enum {
+    RADHIP_OK = 0,
+    RADHIP_E_INVALID = -1,    /* bad argument                                  */
+    RADHIP_E_NO_DEVICE = -2,  /* no gfx950 device / HIP runtime unavailable    */
+    RADHIP_E_HIP = -3,        /* a HIP runtime call failed                     */
+    RADHIP_E_NOMEM = -4,      /* host or device allocation failed              */
+    RADHIP_E_STATE = -5,      /* call order violated (e.g. no graph loaded)    */
+    RADHIP_E_CAPACITY = -6,   /* a fixed-capacity device structure overflowed  */
+    RADHIP_E_RANGE = -7,      /* slot / level out of range                     */
+    RADHIP_E_COMM = -8        /* RCCL failure                                  */
+};
+
+/* ---- library ----------------------------------------------------------- */
+const char *radhip_last_error(void);
+const char *radhip_backend_name(void); /* "hip:gfx950" */
+int radhip_abi_version(void);
+int radhip_device_count(int *out_count);
+
+/* ---- index: corpus + layered adjacency resident in HBM ----------------- */
+typedef struct radhip_index radhip_index_t;
+
+typedef struct {
+    uint64_t n;              /* nodes                                        */
+    uint32_t ndim_bits;
+    uint32_t row_bytes;      /* ceil(ndim/8): what the host passes            */
+    uint32_t row_stride;     /* bytes per row in HBM (16-B lanes, pow2 count) */
+    uint32_t connectivity;   /* upper-level row width                         */
+    uint32_t connectivity_base; /* level-0 row width                          */
+    uint32_t expansion_add;
+    int32_t max_level;       /* 0-based top level, -1 when empty              */
+    uint32_t entry;          /* entry slot                                    */
+    uint64_t n_upper_rows;
+    uint64_t device_bytes;   /* HBM held by this index                        */
+    int32_t device;
+    int32_t has_vectors;
+    int32_t has_graph;
+} radhip_index_info_t;
+
+/* replaces usearch Index(ndim=, dtype='b1', metric='tanimoto', connectivity=,
+ * expansion_add=) — README.md:47-53, scripts/start_hnsw_server.py:44-50.
+ * connectivity_base = 0 selects 2*connectivity.  No device call is made. */
+int radhip_index_create(uint32_t ndim_bits, uint32_t connectivity,
+                        uint32_t connectivity_base, uint32_t expansion_add,
+                        int device, radhip_index_t **out);
+int radhip_index_destroy(radhip_index_t *idx);
+int radhip_index_info(const radhip_index_t *idx, radhip_index_info_t *out);
+
+/* corpus upload (host rows of row_bytes each) — the vector half of
+ * usearch Index.add(keys, fps), README.md:58 */
+int radhip_index_load_vectors(radhip_index_t *idx, const uint8_t *rows, uint64_t n);
+/* closed-form synthetic corpus generated on the device (bench configs 2-4:
+ * avoids a 12.8 GB host transfer).  rows [first_row, first_row+n) of a
+ * logical corpus of n_total rows; mode 0 = Bernoulli(0.5) bits, 1 = clustered
+ * sparse (ECFP-like, ~7 % density). */
+int radhip_index_synth_vectors(radhip_index_t *idx, uint64_t n, uint64_t first_row,
+                               uint64_t n_total, uint64_t seed, int mode);
+int radhip_index_read_vectors(const radhip_index_t *idx, uint64_t first, uint64_t count,
+                              uint8_t *out_rows);
+
+/* adjacency upload: levels[n] (int8), adj0[n*connectivity_base] and
+ * adjU[n_upper_rows*connectivity] padded with RADHIP_NO_SLOT, upper_row[n] =
+ * first upper row of a node (its level-l list is row upper_row+l-1) or
+ * RADHIP_NO_SLOT.  Rows must not contain duplicates or the node itself.
+ * This is what loading a saved graph (usearch Index(path=, view=True,
+ * exclude_vectors=True), scripts/start_hnsw_server.py:69) feeds. */
+int radhip_index_load_graph(radhip_index_t *idx, uint64_t n, int32_t max_level,
+                            uint32_t entry, const int8_t *levels, const uint32_t *adj0,
+                            const uint32_t *upper_row, const uint32_t *adjU,
+                            uint64_t n_upper_rows);
+/* closed-form synthetic layered graph over the n rows already in the index
+ * (bench configs 3-4; labelled synthetic everywhere it is reported) */
+int radhip_index_synth_graph(radhip_index_t *idx, uint64_t seed);
+/* sizes for the read-back buffers are in radhip_index_info */
+int radhip_index_read_graph(const radhip_index_t *idx, int8_t *levels, uint32_t *adj0,
+                            uint32_t *upper_row, uint32_t *adjU);
+
+/* replaces index.get_neighbors(node_id, level) — rad/hnsw_service.py:222,
+ * rad/hnsw_server.py:483: writes the neighbor slots of (slot, level) in stored
+ * order; RADHIP_E_RANGE if the node does not exist on that level. */
+int radhip_get_neighbors(const radhip_index_t *idx, uint32_t slot, int32_t level,
+                         uint32_t *out_slots, uint32_t cap, uint32_t *out_n);
+/* replaces index.get_top_level_nodes() — rad/hnsw_service.py:229,
+ * rad/hnsw_server.py:196: slots with level == max_level, ascending. */
+int radhip_get_top_level_nodes(const radhip_index_t *idx, uint32_t *out_slots,
+                               uint64_t cap, uint64_t *out_n);
+
+/* ---- A1: Tanimoto kernels (usearch metric='tanimoto', dtype='b1') ------ */
+/* K1: nq queries x rows [first, first+count): and_out/or_out are [nq*count]
+ * host arrays, query-major. */
+int radhip_tanimoto_scan(radhip_index_t *idx, const uint8_t *queries, uint32_t nq,
+                         uint64_t first, uint64_t count, uint32_t *and_out,
+                         uint32_t *or_out);
+/* K2: candidate lists.  cand_offsets[nq+1] delimits each query's slots. */
+int radhip_tanimoto_gather(radhip_index_t *idx, const uint8_t *queries, uint32_t nq,
+                           const uint32_t *cand_slots, const uint64_t *cand_offsets,
+                           uint32_t *and_out, uint32_t *or_out);
+/* float edge value: 1.0f - (float)and/(float)or, 0.0f when or == 0 */
+float radhip_distance_f32(uint32_t and_cnt, uint32_t or_cnt);
+
+/* ---- A5-A10: RAD best-first traversal, Tanimoto-scored, on the device --- */
+/* One independent traversal per query: prime (rad/traverser.py:128-176) from
+ * the top-level nodes at level max(0, max_level-1), then pop-min / expand /
+ * visited test-and-set / score-if-unscored / insert / descend
+ * (rad/coordination_service.py:290-413, rad/distributed_worker.py:272-333)
+ * with scoring_fn = Tanimoto distance to the query, until n_to_score nodes are
+ * scored (checked before every pop) or the queue is empty. */
+typedef struct radhip_traversal radhip_traversal_t;
+
+typedef struct {
+    uint64_t n_scored;   /* nodes in the scored set (== Tanimoto evaluations) */
+    uint64_t n_pops;     /* node expansions                                   */
+    uint64_t n_nbr;      /* adjacency entries examined                        */
+    int32_t status;      /* 0 running, 1 done(n_to_score), 2 done(queue empty),
+                            negative RADHIP_E_* on a device-side failure       */
+    int32_t reserved;
+} radhip_trav_stats_t;
+
+#define RADHIP_TRAV_LOG_POPS 1u  /* keep the (node, level) expansion log      */
+
+int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queries, uint32_t nq,
+                            uint64_t n_to_score, uint32_t flags,
+                            radhip_traversal_t **out);
+int radhip_traversal_destroy(radhip_traversal_t *t);
+/* re-arm the same state for a new set of nq queries (bench steps) */
+int radhip_traversal_reset(radhip_traversal_t *t, const uint8_t *queries);
+/* advance every unfinished traversal by at most max_pops expansions
+ * (0 = run to completion); returns the number still running. */
+int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, uint32_t *out_running);
+int radhip_traversal_stats(const radhip_traversal_t *t, radhip_trav_stats_t *out /* [nq] */);
+/* scored set of traversal q in insertion (traversal) order —
+ * rad/scored.py:63-85 get_molecules; scores as integer (and, or) counts */
+int radhip_traversal_results(const radhip_traversal_t *t, uint32_t q, uint32_t *out_slots,
+                             uint32_t *out_and, uint32_t *out_or, uint64_t cap,
+                             uint64_t *out_n);
+int radhip_traversal_pop_log(const radhip_traversal_t *t, uint32_t q, uint32_t *out_nodes,
+                             uint8_t *out_levels, uint64_t cap, uint64_t *out_n);
+/* device time of the traversal kernel launches since create/reset, measured
+ * with HIP events on the library's stream */
+int radhip_traversal_kernel_time(const radhip_traversal_t *t, double *out_ms,
+                                 uint64_t *out_launches);
+uint64_t radhip_traversal_state_bytes(const radhip_traversal_t *t);
+
+/* host restatement of the device queue key, exported so CPU tests can check
+ * its order against the Redis ZSET order of rad/priority_queue.py:22-42
+ * (ascending score, ties by bytes of "{node_id}:{level}") */
+uint64_t radhip_rad_key(uint32_t and_cnt, uint32_t or_cnt, uint32_t slot, uint32_t level);
+void radhip_rad_key_decode(uint64_t key, uint32_t *slot, uint32_t *level);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,121 @@
+"""ctypes binding of librad_hip.so (the C ABI declared in include/rad_hip.h).
+
+There is no CPU fallback: if the shared library is missing this module raises,
+and every device entry point raises ``RadHipError`` when no gfx950 GPU is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "librad_hip.so")
+
+NO_SLOT = 0xFFFFFFFF
+TRAV_LOG_POPS = 1
+
+E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_STATE, E_CAPACITY, E_RANGE, E_COMM = range(-1, -9, -1)
+
+
+class RadHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"librad_hip error {code}: {message}")
+        self.code = code
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("ndim_bits", C.c_uint32), ("row_bytes", C.c_uint32),
+                ("row_stride", C.c_uint32), ("connectivity", C.c_uint32),
+                ("connectivity_base", C.c_uint32), ("expansion_add", C.c_uint32),
+                ("max_level", C.c_int32), ("entry", C.c_uint32), ("n_upper_rows", C.c_uint64),
+                ("device_bytes", C.c_uint64), ("device", C.c_int32), ("has_vectors", C.c_int32),
+                ("has_graph", C.c_int32)]
+
+
+class TravStats(C.Structure):
+    _fields_ = [("n_scored", C.c_uint64), ("n_pops", C.c_uint64), ("n_nbr", C.c_uint64),
+                ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+_P = C.c_void_p
+_U32, _U64, _I32 = C.c_uint32, C.c_uint64, C.c_int32
+
+# name -> (restype, argtypes); every symbol include/rad_hip.h declares
+SIGNATURES = {
+    "radhip_last_error": (C.c_char_p, []),
+    "radhip_backend_name": (C.c_char_p, []),
+    "radhip_abi_version": (C.c_int, []),
+    "radhip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "radhip_index_create": (C.c_int, [_U32, _U32, _U32, _U32, C.c_int, C.POINTER(_P)]),
+    "radhip_index_destroy": (C.c_int, [_P]),
+    "radhip_index_info": (C.c_int, [_P, C.POINTER(IndexInfo)]),
+    "radhip_index_load_vectors": (C.c_int, [_P, _P, _U64]),
+    "radhip_index_synth_vectors": (C.c_int, [_P, _U64, _U64, _U64, _U64, C.c_int]),
+    "radhip_index_read_vectors": (C.c_int, [_P, _U64, _U64, _P]),
+    "radhip_index_load_graph": (C.c_int, [_P, _U64, _I32, _U32, _P, _P, _P, _P, _U64]),
+    "radhip_index_synth_graph": (C.c_int, [_P, _U64]),
+    "radhip_index_read_graph": (C.c_int, [_P, _P, _P, _P, _P]),
+    "radhip_get_neighbors": (C.c_int, [_P, _U32, _I32, _P, _U32, C.POINTER(_U32)]),
+    "radhip_get_top_level_nodes": (C.c_int, [_P, _P, _U64, C.POINTER(_U64)]),
+    "radhip_tanimoto_scan": (C.c_int, [_P, _P, _U32, _U64, _U64, _P, _P]),
+    "radhip_tanimoto_gather": (C.c_int, [_P, _P, _U32, _P, _P, _P, _P]),
+    "radhip_distance_f32": (C.c_float, [_U32, _U32]),
+    "radhip_traversal_create": (C.c_int, [_P, _P, _U32, _U64, _U32, C.POINTER(_P)]),
+    "radhip_traversal_destroy": (C.c_int, [_P]),
+    "radhip_traversal_reset": (C.c_int, [_P, _P]),
+    "radhip_traversal_run": (C.c_int, [_P, _U64, C.POINTER(_U32)]),
+    "radhip_traversal_stats": (C.c_int, [_P, _P]),
+    "radhip_traversal_results": (C.c_int, [_P, _U32, _P, _P, _P, _U64, C.POINTER(_U64)]),
+    "radhip_traversal_pop_log": (C.c_int, [_P, _U32, _P, _P, _U64, C.POINTER(_U64)]),
+    "radhip_traversal_kernel_time": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_U64)]),
+    "radhip_traversal_state_bytes": (_U64, [_P]),
+    "radhip_rad_key": (_U64, [_U32, _U32, _U32, _U32]),
+    "radhip_rad_key_decode": (None, [_U64, C.POINTER(_U32), C.POINTER(_U32)]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load librad_hip.so; raises if it was not built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` or `make -C rad_amd/csrc` (hipcc, gfx950). rad_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if L.radhip_abi_version() != 1:
+            raise ImportError("librad_hip ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RadHipError(rc, lib().radhip_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib().radhip_device_count(C.byref(n)))
+    return n.value
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def as_rows(a, row_bytes: int, what: str = "vectors") -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    if a.ndim != 2 or a.shape[1] != row_bytes:
+        raise ValueError(f"{what} must have shape (n, {row_bytes}) uint8 (np.packbits output), got {a.shape}")
+    return a

@@ -1,0 +1,135 @@
+// common.h — shared host/device helpers of librad_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/rad_hip.h"
+
+// ---------------------------------------------------------------- errors --
+void radhip_set_error(const char *fmt, ...);
+
+#define RH_FAIL(code, ...)            \
+    do {                              \
+        radhip_set_error(__VA_ARGS__); \
+        return (code);                \
+    } while (0)
+
+#define RH_HIP(expr)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            radhip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                 \
+            return (e_ == hipErrorOutOfMemory) ? RADHIP_E_NOMEM : RADHIP_E_HIP;   \
+        }                                                                         \
+    } while (0)
+
+#define RH_TRY(expr)            \
+    do {                        \
+        int rc_ = (expr);       \
+        if (rc_ != RADHIP_OK) return rc_; \
+    } while (0)
+
+// ------------------------------------------------------------- the index --
+struct radhip_index {
+    uint32_t ndim_bits = 0, row_bytes = 0, row_stride = 0, lpr = 0;  // lpr = 16-B lanes per row
+    uint32_t M = 0, cap0 = 0, ef_add = 0;
+    int device = 0;
+    uint64_t n = 0;           // rows in the corpus
+    // ---- host mirror (adjacency reads need no device: fork-safe) ----------
+    uint64_t g_n = 0;         // nodes in the graph
+    int32_t max_level = -1;
+    uint32_t entry = RADHIP_NO_SLOT;
+    uint64_t n_upper_rows = 0;
+    std::vector<int8_t> h_levels;
+    std::vector<uint32_t> h_adj0, h_upper_row, h_adjU, h_top;
+    bool h_graph_valid = false;   // host mirror holds the graph
+    std::vector<uint8_t> h_rows;  // staged corpus awaiting upload (freed after)
+    bool h_rows_pending = false;
+    bool has_graph = false, has_vectors = false;
+    // ---- device ------------------------------------------------------------
+    bool dev_ready = false;
+    hipStream_t stream = nullptr;
+    uint4 *d_fp = nullptr;        // [n * lpr]
+    int8_t *d_levels = nullptr;   // [g_n]
+    uint32_t *d_adj0 = nullptr;   // [g_n * cap0]
+    uint32_t *d_upper_row = nullptr;
+    uint32_t *d_adjU = nullptr;   // [n_upper_rows * M]
+    uint32_t *d_top = nullptr;    // top-level slots
+    uint32_t n_top = 0;
+    bool d_graph_valid = false;
+    uint64_t fp_cap_rows = 0;
+    uint64_t device_bytes = 0;
+    std::mutex mu;
+};
+
+int rh_ensure_device(radhip_index *idx);           // lazy HIP init + pending uploads
+int rh_ensure_host_graph(radhip_index *idx);       // D2H mirror of a device-generated graph
+
+// ------------------------------------------------- device-side primitives --
+#define RH_WAVE 64
+
+__device__ __forceinline__ uint32_t rh_popc4(const uint4 v) {
+    return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+}
+__device__ __forceinline__ uint32_t rh_popc4_and(const uint4 a, const uint4 b) {
+    return __popc(a.x & b.x) + __popc(a.y & b.y) + __popc(a.z & b.z) + __popc(a.w & b.w);
+}
+// sum over groups of LPR adjacent lanes; every lane of the group gets the total
+template <int LPR>
+__device__ __forceinline__ uint32_t rh_group_sum(uint32_t v) {
+#pragma unroll
+    for (int m = 1; m < LPR; m <<= 1) v += __shfl_xor(v, m, RH_WAVE);
+    return v;
+}
+
+// ---------------------------------------------------- RAD queue key (u64) --
+// Order = Redis ZSET order of rad/priority_queue.py:22-42 for a Tanimoto score:
+//   ascending score, ties by bytes of the member string "{node_id}:{level}".
+// bits 61..38 q  = floor((or-and) * 2^23 / or): strictly monotone in the exact
+//                  rational distance 1 - and/or for or <= 2048, hence in its
+//                  correctly rounded float32 value (tests/test_key_order.py)
+// bits 37..8  p  = (slot+1) * 10^(9-d) - 1   (d = decimal digits of slot):
+//                  the digits right-padded with '9's
+// bits  7..4  9-d : on equal p the longer decimal string sorts first (':' > '9')
+// bits  3..0  rank of the level string in bytewise order ("10" < "2")
+#define RH_KEY_INF 0xFFFFFFFFFFFFFFFFull
+
+__host__ __device__ __forceinline__ uint32_t rh_q24(uint32_t a, uint32_t o) {
+    if (o == 0) return 0;
+    // exact: the true quotient is either an integer or >= 2^-11 away from one,
+    // the double division error is < 2^-29
+    return (uint32_t)((double)((uint64_t)(o - a) << 23) / (double)o);
+}
+__host__ __device__ __forceinline__ uint32_t rh_level_rank(uint32_t level) {
+    return level < 2 ? level : (level >= 10 ? level - 8 : level + 6);
+}
+__host__ __device__ __forceinline__ uint32_t rh_rank_level(uint32_t r) {
+    return r < 2 ? r : (r <= 7 ? r + 8 : r - 6);
+}
+__host__ __device__ __forceinline__ uint32_t rh_pow10(uint32_t e) {
+    uint32_t p = 1;
+    p = e >= 8 ? 100000000u : e == 7 ? 10000000u : e == 6 ? 1000000u : e == 5 ? 100000u
+      : e == 4 ? 10000u : e == 3 ? 1000u : e == 2 ? 100u : e == 1 ? 10u : p;
+    return p;
+}
+__host__ __device__ __forceinline__ uint64_t rh_make_key(uint32_t q24, uint32_t slot, uint32_t level) {
+    uint32_t d = 1 + (slot >= 10u) + (slot >= 100u) + (slot >= 1000u) + (slot >= 10000u) +
+                 (slot >= 100000u) + (slot >= 1000000u) + (slot >= 10000000u) + (slot >= 100000000u);
+    uint32_t dl = 9 - d;
+    uint32_t p = (slot + 1u) * rh_pow10(dl) - 1u;
+    return ((uint64_t)q24 << 38) | ((uint64_t)p << 8) | ((uint64_t)dl << 4) | (uint64_t)rh_level_rank(level);
+}
+__host__ __device__ __forceinline__ void rh_decode_key(uint64_t key, uint32_t *slot, uint32_t *level) {
+    uint32_t p = (uint32_t)(key >> 8) & 0x3FFFFFFFu;
+    uint32_t dl = (uint32_t)(key >> 4) & 0xFu;
+    *slot = (p + 1u) / rh_pow10(dl) - 1u;
+    *level = rh_rank_level((uint32_t)key & 0xFu);
+}

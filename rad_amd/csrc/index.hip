@@ -1,0 +1,725 @@
+// index.hip — index object (corpus + layered adjacency in HBM), synthetic
+// generators, K1 scan and K2 gather Tanimoto kernels.  gfx950 only.
+#include "common.h"
+
+#include <algorithm>
+#include <new>
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void radhip_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *radhip_last_error(void) { return g_err; }
+extern "C" const char *radhip_backend_name(void) { return "hip:gfx950"; }
+extern "C" int radhip_abi_version(void) { return RADHIP_ABI_VERSION; }
+
+extern "C" int radhip_device_count(int *out_count) {
+    if (!out_count) RH_FAIL(RADHIP_E_INVALID, "out_count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    *out_count = n;
+    return RADHIP_OK;
+}
+
+extern "C" float radhip_distance_f32(uint32_t a, uint32_t o) {
+    if (o == 0) return 0.0f;
+    volatile float q = (float)a / (float)o;
+    return 1.0f - q;
+}
+
+extern "C" uint64_t radhip_rad_key(uint32_t a, uint32_t o, uint32_t slot, uint32_t level) {
+    return rh_make_key(rh_q24(a, o), slot, level);
+}
+extern "C" void radhip_rad_key_decode(uint64_t key, uint32_t *slot, uint32_t *level) {
+    rh_decode_key(key, slot, level);
+}
+
+// --------------------------------------------------------------- lifecycle
+extern "C" int radhip_index_create(uint32_t ndim_bits, uint32_t connectivity,
+                                   uint32_t connectivity_base, uint32_t expansion_add,
+                                   int device, radhip_index_t **out) {
+    if (!out) RH_FAIL(RADHIP_E_INVALID, "out is null");
+    if (ndim_bits == 0 || ndim_bits > 2048) RH_FAIL(RADHIP_E_INVALID, "ndim_bits must be in 1..2048 (got %u)", ndim_bits);
+    if (connectivity < 2 || connectivity > 64) RH_FAIL(RADHIP_E_INVALID, "connectivity must be in 2..64 (got %u)", connectivity);
+    if (connectivity_base == 0) connectivity_base = 2 * connectivity;
+    if (connectivity_base > 64) RH_FAIL(RADHIP_E_INVALID, "connectivity_base must be <= 64 (got %u)", connectivity_base);
+    radhip_index *idx = new (std::nothrow) radhip_index();
+    if (!idx) RH_FAIL(RADHIP_E_NOMEM, "out of host memory");
+    idx->ndim_bits = ndim_bits;
+    idx->row_bytes = (ndim_bits + 7) / 8;
+    uint32_t chunks = (idx->row_bytes + 15) / 16, lpr = 1;
+    while (lpr < chunks) lpr <<= 1;
+    idx->lpr = lpr;
+    idx->row_stride = lpr * 16;
+    idx->M = connectivity;
+    idx->cap0 = connectivity_base;
+    idx->ef_add = expansion_add;
+    idx->device = device;
+    *out = idx;
+    return RADHIP_OK;
+}
+
+static void free_dev(radhip_index *idx) {
+    if (!idx->dev_ready) return;
+    (void)hipSetDevice(idx->device);
+    if (idx->d_fp) (void)hipFree(idx->d_fp);
+    if (idx->d_levels) (void)hipFree(idx->d_levels);
+    if (idx->d_adj0) (void)hipFree(idx->d_adj0);
+    if (idx->d_upper_row) (void)hipFree(idx->d_upper_row);
+    if (idx->d_adjU) (void)hipFree(idx->d_adjU);
+    if (idx->d_top) (void)hipFree(idx->d_top);
+    if (idx->stream) (void)hipStreamDestroy(idx->stream);
+    idx->d_fp = nullptr; idx->d_levels = nullptr; idx->d_adj0 = nullptr;
+    idx->d_upper_row = nullptr; idx->d_adjU = nullptr; idx->d_top = nullptr;
+    idx->stream = nullptr;
+}
+
+extern "C" int radhip_index_destroy(radhip_index_t *idx) {
+    if (!idx) return RADHIP_OK;
+    free_dev(idx);
+    delete idx;
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_index_info(const radhip_index_t *idx, radhip_index_info_t *o) {
+    if (!idx || !o) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    memset(o, 0, sizeof *o);
+    o->n = idx->has_graph ? idx->g_n : idx->n;
+    if (idx->has_vectors && idx->n > o->n) o->n = idx->n;
+    o->ndim_bits = idx->ndim_bits; o->row_bytes = idx->row_bytes; o->row_stride = idx->row_stride;
+    o->connectivity = idx->M; o->connectivity_base = idx->cap0; o->expansion_add = idx->ef_add;
+    o->max_level = idx->max_level; o->entry = idx->entry; o->n_upper_rows = idx->n_upper_rows;
+    o->device_bytes = idx->device_bytes; o->device = idx->device;
+    o->has_vectors = idx->has_vectors; o->has_graph = idx->has_graph;
+    return RADHIP_OK;
+}
+
+static int dev_alloc(radhip_index *idx, void **p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    RH_HIP(hipMalloc(p, bytes));
+    idx->device_bytes += bytes;
+    return RADHIP_OK;
+}
+static void dev_free(radhip_index *idx, void *p, size_t bytes) {
+    if (!p) return;
+    (void)hipFree(p);
+    idx->device_bytes -= std::min<uint64_t>(idx->device_bytes, bytes ? bytes : 16);
+}
+
+static int alloc_graph_dev(radhip_index *idx) {
+    dev_free(idx, idx->d_levels, idx->g_n); idx->d_levels = nullptr;
+    // sizes of the previous graph are not tracked separately; a graph is
+    // (re)loaded rarely, so the accounting is reset by the caller when needed
+    if (idx->d_adj0) { (void)hipFree(idx->d_adj0); idx->d_adj0 = nullptr; }
+    if (idx->d_upper_row) { (void)hipFree(idx->d_upper_row); idx->d_upper_row = nullptr; }
+    if (idx->d_adjU) { (void)hipFree(idx->d_adjU); idx->d_adjU = nullptr; }
+    if (idx->d_top) { (void)hipFree(idx->d_top); idx->d_top = nullptr; }
+    RH_TRY(dev_alloc(idx, (void **)&idx->d_levels, idx->g_n));
+    RH_TRY(dev_alloc(idx, (void **)&idx->d_adj0, idx->g_n * idx->cap0 * 4));
+    RH_TRY(dev_alloc(idx, (void **)&idx->d_upper_row, idx->g_n * 4));
+    RH_TRY(dev_alloc(idx, (void **)&idx->d_adjU, idx->n_upper_rows * idx->M * 4));
+    return RADHIP_OK;
+}
+
+static int upload_top(radhip_index *idx) {
+    if (idx->d_top) { (void)hipFree(idx->d_top); idx->d_top = nullptr; }
+    idx->n_top = (uint32_t)idx->h_top.size();
+    RH_TRY(dev_alloc(idx, (void **)&idx->d_top, (size_t)idx->n_top * 4));
+    if (idx->n_top)
+        RH_HIP(hipMemcpy(idx->d_top, idx->h_top.data(), (size_t)idx->n_top * 4, hipMemcpyHostToDevice));
+    return RADHIP_OK;
+}
+
+int rh_ensure_device(radhip_index *idx) {
+    if (!idx->dev_ready) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+            RH_FAIL(RADHIP_E_NO_DEVICE, "no HIP device visible: librad_hip has no CPU fallback");
+        if (idx->device < 0 || idx->device >= n)
+            RH_FAIL(RADHIP_E_NO_DEVICE, "device %d out of range (%d visible)", idx->device, n);
+        RH_HIP(hipSetDevice(idx->device));
+        hipDeviceProp_t prop;
+        RH_HIP(hipGetDeviceProperties(&prop, idx->device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            RH_FAIL(RADHIP_E_NO_DEVICE, "device %d is %s; librad_hip is built for gfx950 only", idx->device, prop.gcnArchName);
+        RH_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+        idx->dev_ready = true;
+    }
+    RH_HIP(hipSetDevice(idx->device));
+    if (idx->h_rows_pending) {
+        if (idx->d_fp) { dev_free(idx, idx->d_fp, idx->fp_cap_rows * idx->row_stride); idx->d_fp = nullptr; }
+        RH_TRY(dev_alloc(idx, (void **)&idx->d_fp, idx->n * idx->row_stride));
+        idx->fp_cap_rows = idx->n;
+        RH_HIP(hipMemcpy(idx->d_fp, idx->h_rows.data(), idx->n * idx->row_stride, hipMemcpyHostToDevice));
+        std::vector<uint8_t>().swap(idx->h_rows);
+        idx->h_rows_pending = false;
+    }
+    if (idx->has_graph && !idx->d_graph_valid) {
+        // graph came from the host (load_graph): upload it
+        RH_TRY(alloc_graph_dev(idx));
+        RH_HIP(hipMemcpy(idx->d_levels, idx->h_levels.data(), idx->g_n, hipMemcpyHostToDevice));
+        RH_HIP(hipMemcpy(idx->d_adj0, idx->h_adj0.data(), idx->g_n * idx->cap0 * 4, hipMemcpyHostToDevice));
+        RH_HIP(hipMemcpy(idx->d_upper_row, idx->h_upper_row.data(), idx->g_n * 4, hipMemcpyHostToDevice));
+        if (idx->n_upper_rows)
+            RH_HIP(hipMemcpy(idx->d_adjU, idx->h_adjU.data(), idx->n_upper_rows * idx->M * 4, hipMemcpyHostToDevice));
+        RH_TRY(upload_top(idx));
+        idx->d_graph_valid = true;
+    }
+    return RADHIP_OK;
+}
+
+int rh_ensure_host_graph(radhip_index *idx) {
+    if (!idx->has_graph) RH_FAIL(RADHIP_E_STATE, "no graph loaded");
+    if (idx->h_graph_valid) return RADHIP_OK;
+    RH_TRY(rh_ensure_device(idx));
+    idx->h_levels.resize(idx->g_n);
+    idx->h_adj0.resize(idx->g_n * idx->cap0);
+    idx->h_upper_row.resize(idx->g_n);
+    idx->h_adjU.resize(idx->n_upper_rows * idx->M);
+    RH_HIP(hipMemcpy(idx->h_levels.data(), idx->d_levels, idx->g_n, hipMemcpyDeviceToHost));
+    RH_HIP(hipMemcpy(idx->h_adj0.data(), idx->d_adj0, idx->g_n * idx->cap0 * 4, hipMemcpyDeviceToHost));
+    RH_HIP(hipMemcpy(idx->h_upper_row.data(), idx->d_upper_row, idx->g_n * 4, hipMemcpyDeviceToHost));
+    if (idx->n_upper_rows)
+        RH_HIP(hipMemcpy(idx->h_adjU.data(), idx->d_adjU, idx->n_upper_rows * idx->M * 4, hipMemcpyDeviceToHost));
+    idx->h_graph_valid = true;
+    return RADHIP_OK;
+}
+
+// ------------------------------------------------------------------ corpus
+extern "C" int radhip_index_load_vectors(radhip_index_t *idx, const uint8_t *rows, uint64_t n) {
+    if (!idx || (!rows && n)) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    try {
+        idx->h_rows.assign((size_t)n * idx->row_stride, 0);
+    } catch (...) {
+        RH_FAIL(RADHIP_E_NOMEM, "out of host memory staging %llu rows", (unsigned long long)n);
+    }
+    const uint32_t tail_bits = idx->ndim_bits % 8;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint8_t *dst = idx->h_rows.data() + i * idx->row_stride;
+        memcpy(dst, rows + i * idx->row_bytes, idx->row_bytes);
+        (void)tail_bits;  // padding bits beyond ndim are the caller's (np.packbits zero-fills them)
+    }
+    idx->n = n;
+    idx->h_rows_pending = true;
+    idx->has_vectors = true;
+    return RADHIP_OK;
+}
+
+// splitmix-style hashing shared (by restatement) with oracle/rad_oracle.c
+__host__ __device__ __forceinline__ uint64_t syn_mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t syn_h3(uint64_t seed, uint64_t a, uint64_t b) {
+    return syn_mix64(syn_mix64(seed ^ (a * 0xD6E8FEB86659FD93ULL)) + b);
+}
+__host__ __device__ __forceinline__ uint64_t syn_sparse(uint64_t seed, uint64_t a, uint64_t b, int k) {
+    uint64_t w = ~0ULL;
+    for (int t = 0; t < k; ++t) w &= syn_h3(seed + (uint64_t)t * 0x100000001B3ULL, a, b);
+    return w;
+}
+#define SYN_CS 32ull
+#define SYN_SC 64ull
+#define SYN_TAG_S 0x5355504552ULL
+#define SYN_TAG_CD 0x434C5544ULL
+#define SYN_TAG_CA 0x434C5541ULL
+#define SYN_TAG_RD 0x524F5744ULL
+#define SYN_TAG_RA 0x524F5741ULL
+#define SYN_TAG_G0 0x4752415048ULL
+
+__host__ __device__ __forceinline__ uint64_t syn_nc(uint64_t n) {
+    uint64_t nc = n / SYN_CS;
+    return nc ? nc : 1;
+}
+__device__ __forceinline__ uint64_t syn_word(uint64_t seed, uint64_t row, uint64_t n_total, uint32_t w, int mode) {
+    if (mode == 0) return syn_h3(seed, row, w);
+    uint64_t nc = syn_nc(n_total);
+    uint64_t c = row % nc, s = c / SYN_SC;
+    uint64_t sb = syn_sparse(seed ^ SYN_TAG_S, s, w, 4);
+    uint64_t cb = (sb & ~syn_sparse(seed ^ SYN_TAG_CD, c, w, 2)) | syn_sparse(seed ^ SYN_TAG_CA, c, w, 6);
+    return (cb & ~syn_sparse(seed ^ SYN_TAG_RD, row, w, 3)) | syn_sparse(seed ^ SYN_TAG_RA, row, w, 6);
+}
+
+// one thread per 64-bit word of the padded row
+__global__ void synth_rows_kernel(uint64_t *fp, uint64_t n, uint32_t words_per_stride, uint32_t row_bytes,
+                                  uint32_t ndim_bits, uint64_t first_row, uint64_t n_total,
+                                  uint64_t seed, int mode) {
+    uint64_t total = n * words_per_stride;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t r = i / words_per_stride;
+        uint32_t w = (uint32_t)(i % words_per_stride);
+        uint64_t x = 0;
+        if (w * 8u < row_bytes) {
+            x = syn_word(seed, first_row + r, n_total, w, mode);
+            uint32_t take = row_bytes - w * 8u;
+            if (take < 8u) x &= (1ull << (take * 8u)) - 1ull;
+            if ((ndim_bits % 8u) && (w * 8u + 8u >= row_bytes)) {
+                // clear the bits above ndim in the last byte
+                uint32_t last = row_bytes - 1u - w * 8u;
+                uint64_t keep = ((1ull << (ndim_bits % 8u)) - 1ull) << (last * 8u);
+                uint64_t below = last ? ((1ull << (last * 8u)) - 1ull) : 0ull;
+                x &= (keep | below);
+            }
+        }
+        fp[i] = x;
+    }
+}
+
+extern "C" int radhip_index_synth_vectors(radhip_index_t *idx, uint64_t n, uint64_t first_row,
+                                          uint64_t n_total, uint64_t seed, int mode) {
+    if (!idx) RH_FAIL(RADHIP_E_INVALID, "null index");
+    if (mode != 0 && mode != 1) RH_FAIL(RADHIP_E_INVALID, "mode must be 0 or 1");
+    if (first_row + n > n_total) RH_FAIL(RADHIP_E_INVALID, "rows [first, first+n) exceed n_total");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    idx->h_rows_pending = false;
+    std::vector<uint8_t>().swap(idx->h_rows);
+    RH_TRY(rh_ensure_device(idx));
+    if (idx->d_fp) { dev_free(idx, idx->d_fp, idx->fp_cap_rows * idx->row_stride); idx->d_fp = nullptr; }
+    RH_TRY(dev_alloc(idx, (void **)&idx->d_fp, n * idx->row_stride));
+    idx->fp_cap_rows = n;
+    idx->n = n;
+    uint32_t wps = idx->row_stride / 8;
+    hipLaunchKernelGGL(synth_rows_kernel, dim3(256 * 16), dim3(256), 0, idx->stream, (uint64_t *)idx->d_fp, n,
+                       wps, idx->row_bytes, idx->ndim_bits, first_row, n_total, seed, mode);
+    RH_HIP(hipGetLastError());
+    RH_HIP(hipStreamSynchronize(idx->stream));
+    idx->has_vectors = true;
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_index_read_vectors(const radhip_index_t *cidx, uint64_t first, uint64_t count,
+                                         uint8_t *out_rows) {
+    radhip_index *idx = const_cast<radhip_index *>(cidx);
+    if (!idx || !out_rows) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (!idx->has_vectors) RH_FAIL(RADHIP_E_STATE, "no vectors loaded");
+    if (first + count > idx->n) RH_FAIL(RADHIP_E_RANGE, "rows out of range");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_TRY(rh_ensure_device(idx));
+    if (idx->row_bytes == idx->row_stride) {
+        RH_HIP(hipMemcpy(out_rows, (const uint8_t *)idx->d_fp + first * idx->row_stride,
+                         count * idx->row_stride, hipMemcpyDeviceToHost));
+    } else {
+        RH_HIP(hipMemcpy2D(out_rows, idx->row_bytes, (const uint8_t *)idx->d_fp + first * idx->row_stride,
+                           idx->row_stride, idx->row_bytes, count, hipMemcpyDeviceToHost));
+    }
+    return RADHIP_OK;
+}
+
+// ------------------------------------------------------------------- graph
+static void compute_top(radhip_index *idx) {
+    idx->h_top.clear();
+    for (uint64_t i = 0; i < idx->g_n; ++i)
+        if (idx->h_levels[i] == idx->max_level) idx->h_top.push_back((uint32_t)i);
+}
+
+extern "C" int radhip_index_load_graph(radhip_index_t *idx, uint64_t n, int32_t max_level,
+                                       uint32_t entry, const int8_t *levels, const uint32_t *adj0,
+                                       const uint32_t *upper_row, const uint32_t *adjU,
+                                       uint64_t n_upper_rows) {
+    if (!idx || !levels || !adj0 || !upper_row || (n_upper_rows && !adjU))
+        RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (n == 0 || n >= 0xFFFFFFFFull) RH_FAIL(RADHIP_E_INVALID, "n out of range");
+    if (max_level < 0 || max_level > 15) RH_FAIL(RADHIP_E_INVALID, "max_level must be in 0..15");
+    if (entry >= n) RH_FAIL(RADHIP_E_INVALID, "entry slot out of range");
+    // validate: levels, row ranges, no self / duplicate / out-of-range targets,
+    // every target exists on the level of the row it appears in
+    for (uint64_t i = 0; i < n; ++i) {
+        int lv = levels[i];
+        if (lv < 0 || lv > max_level) RH_FAIL(RADHIP_E_INVALID, "levels[%llu]=%d out of range", (unsigned long long)i, lv);
+        if (lv > 0 && ((uint64_t)upper_row[i] + (uint64_t)lv > n_upper_rows))
+            RH_FAIL(RADHIP_E_INVALID, "upper_row[%llu] out of range", (unsigned long long)i);
+        for (int l = 0; l <= lv; ++l) {
+            const uint32_t cap = l == 0 ? idx->cap0 : idx->M;
+            const uint32_t *row = l == 0 ? adj0 + i * idx->cap0 : adjU + ((uint64_t)upper_row[i] + (l - 1)) * idx->M;
+            bool ended = false;
+            for (uint32_t j = 0; j < cap; ++j) {
+                uint32_t t = row[j];
+                if (t == RADHIP_NO_SLOT) { ended = true; continue; }
+                if (ended) RH_FAIL(RADHIP_E_INVALID, "node %llu level %d: slot after padding", (unsigned long long)i, l);
+                if (t >= n || t == i) RH_FAIL(RADHIP_E_INVALID, "node %llu level %d: bad target %u", (unsigned long long)i, l, t);
+                if (levels[t] < l) RH_FAIL(RADHIP_E_INVALID, "node %llu level %d: target %u absent on that level", (unsigned long long)i, l, t);
+                for (uint32_t k = 0; k < j; ++k)
+                    if (row[k] == t) RH_FAIL(RADHIP_E_INVALID, "node %llu level %d: duplicate target %u", (unsigned long long)i, l, t);
+            }
+        }
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    try {
+        idx->h_levels.assign(levels, levels + n);
+        idx->h_adj0.assign(adj0, adj0 + n * idx->cap0);
+        idx->h_upper_row.assign(upper_row, upper_row + n);
+        idx->h_adjU.assign(adjU, adjU + n_upper_rows * idx->M);
+    } catch (...) {
+        RH_FAIL(RADHIP_E_NOMEM, "out of host memory");
+    }
+    idx->g_n = n; idx->max_level = max_level; idx->entry = entry; idx->n_upper_rows = n_upper_rows;
+    compute_top(idx);
+    idx->h_graph_valid = true;
+    idx->d_graph_valid = false;
+    idx->has_graph = true;
+    return RADHIP_OK;
+}
+
+__host__ __device__ __forceinline__ uint64_t syn_ipow(uint64_t b, int e) {
+    uint64_t r = 1;
+    while (e-- > 0) r *= b;
+    return r;
+}
+static int32_t syn_max_level(uint64_t n, uint32_t M) {
+    int32_t l = 0;
+    uint64_t p = 1;
+    while (l < 15 && p * M < n) { p *= M; l++; }
+    return l;
+}
+
+// one thread per node: level, level-0 row, upper rows (closed form)
+__global__ void synth_graph_kernel(uint64_t n, uint32_t M, uint32_t cap0, int32_t L, uint64_t seed,
+                                   int8_t *levels, uint32_t *adj0, uint32_t *upper_row, uint32_t *adjU) {
+    const uint64_t nc = syn_nc(n);
+    const uint32_t H = cap0 / 2, LK = cap0 - H, LN = LK / 2, LF = LK - LN;
+    const uint64_t gs = seed ^ SYN_TAG_G0;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n;
+         r += (uint64_t)gridDim.x * blockDim.x) {
+        int lv;
+        if (r == 0) lv = L;
+        else { lv = 0; uint64_t x = r; while (lv < L && x % M == 0) { x /= M; lv++; } }
+        levels[r] = (int8_t)lv;
+        uint32_t *row = adj0 + r * cap0;
+        uint32_t k = 0;
+        const uint64_t c = r % nc, m = r / nc;
+        const uint64_t cs = (n - c + nc - 1) / nc;
+        for (uint32_t j = 0; j < H && j + 1 < cs; ++j) row[k++] = (uint32_t)(c + ((m + 1 + j) % cs) * nc);
+        const uint64_t s0 = (c / SYN_SC) * SYN_SC;
+        const uint64_t ss = (s0 + SYN_SC <= nc) ? SYN_SC : nc - s0;
+        for (uint32_t jj = 0; jj < LN; ++jj) {
+            uint64_t off;
+            const uint64_t hh = syn_h3(gs, r, jj);
+            if (ss - 1 >= LN) { uint64_t bw = (ss - 1) / LN; off = 1 + jj * bw + hh % bw; }
+            else if (jj + 1 < ss) off = 1 + jj;
+            else continue;
+            const uint64_t c2 = s0 + ((c - s0) + off) % ss;
+            const uint64_t cs2 = (n - c2 + nc - 1) / nc;
+            row[k++] = (uint32_t)(c2 + ((hh >> 32) % cs2) * nc);
+        }
+        if (nc >= 4 * SYN_SC) {
+            const uint64_t span = nc - 2 * SYN_SC + 1;
+            for (uint32_t jj = 0; jj < LF; ++jj) {
+                const uint64_t hh = syn_h3(gs, r, 1000 + jj);
+                const uint64_t bw = span / LF;
+                const uint64_t off = SYN_SC + jj * bw + hh % bw;
+                const uint64_t c2 = (c + off) % nc;
+                const uint64_t cs2 = (n - c2 + nc - 1) / nc;
+                row[k++] = (uint32_t)(c2 + ((hh >> 32) % cs2) * nc);
+            }
+        }
+        while (k < cap0) row[k++] = RADHIP_NO_SLOT;
+        if (lv == 0) { upper_row[r] = RADHIP_NO_SLOT; continue; }
+        uint64_t base = 0;
+        for (int l = 1; l <= L; ++l) { uint64_t p = syn_ipow(M, l); base += (r + p - 1) / p; }
+        upper_row[r] = (uint32_t)base;
+        for (int l = 1; l <= lv; ++l) {
+            uint32_t *ur = adjU + (base + (uint64_t)(l - 1)) * M;
+            const uint64_t p = syn_ipow(M, l), kk = r / p, nl = (n + p - 1) / p;
+            uint32_t u = 0;
+            for (uint32_t j = 0; j < M; ++j) {
+                uint64_t off;
+                if (nl - 1 >= M) { uint64_t bw = (nl - 1) / M; off = 1 + j * bw + syn_h3(gs, r, 2000 + 64 * (uint64_t)l + j) % bw; }
+                else if (j + 1 < nl) off = 1 + j;
+                else break;
+                ur[u++] = (uint32_t)(((kk + off) % nl) * p);
+            }
+            while (u < M) ur[u++] = RADHIP_NO_SLOT;
+        }
+    }
+}
+
+extern "C" int radhip_index_synth_graph(radhip_index_t *idx, uint64_t seed) {
+    if (!idx) RH_FAIL(RADHIP_E_INVALID, "null index");
+    if (!idx->has_vectors || idx->n == 0) RH_FAIL(RADHIP_E_STATE, "load or generate vectors first");
+    if (idx->n >= 0xFFFFFFFFull) RH_FAIL(RADHIP_E_INVALID, "n too large");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_TRY(rh_ensure_device(idx));
+    const uint64_t n = idx->n;
+    const int32_t L = syn_max_level(n, idx->M);
+    uint64_t nu = 0;
+    for (int l = 1; l <= L; ++l) { uint64_t p = syn_ipow(idx->M, l); nu += (n + p - 1) / p; }
+    idx->g_n = n; idx->max_level = L; idx->entry = 0; idx->n_upper_rows = nu;
+    RH_TRY(alloc_graph_dev(idx));
+    hipLaunchKernelGGL(synth_graph_kernel, dim3(256 * 8), dim3(256), 0, idx->stream, n, idx->M, idx->cap0, L,
+                       seed, idx->d_levels, idx->d_adj0, idx->d_upper_row, idx->d_adjU);
+    RH_HIP(hipGetLastError());
+    RH_HIP(hipStreamSynchronize(idx->stream));
+    // top-level nodes in closed form: multiples of M^L
+    idx->h_top.clear();
+    const uint64_t p = syn_ipow(idx->M, L);
+    for (uint64_t r = 0; r < n; r += p) idx->h_top.push_back((uint32_t)r);
+    RH_TRY(upload_top(idx));
+    idx->h_graph_valid = false;
+    std::vector<int8_t>().swap(idx->h_levels);
+    std::vector<uint32_t>().swap(idx->h_adj0);
+    std::vector<uint32_t>().swap(idx->h_upper_row);
+    std::vector<uint32_t>().swap(idx->h_adjU);
+    idx->d_graph_valid = true;
+    idx->has_graph = true;
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_index_read_graph(const radhip_index_t *cidx, int8_t *levels, uint32_t *adj0,
+                                       uint32_t *upper_row, uint32_t *adjU) {
+    radhip_index *idx = const_cast<radhip_index *>(cidx);
+    if (!idx) RH_FAIL(RADHIP_E_INVALID, "null index");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_TRY(rh_ensure_host_graph(idx));
+    if (levels) memcpy(levels, idx->h_levels.data(), idx->g_n);
+    if (adj0) memcpy(adj0, idx->h_adj0.data(), idx->g_n * idx->cap0 * 4);
+    if (upper_row) memcpy(upper_row, idx->h_upper_row.data(), idx->g_n * 4);
+    if (adjU && idx->n_upper_rows) memcpy(adjU, idx->h_adjU.data(), idx->n_upper_rows * idx->M * 4);
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_get_neighbors(const radhip_index_t *cidx, uint32_t slot, int32_t level,
+                                    uint32_t *out_slots, uint32_t cap, uint32_t *out_n) {
+    radhip_index *idx = const_cast<radhip_index *>(cidx);
+    if (!idx || !out_n) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_TRY(rh_ensure_host_graph(idx));
+    if (slot >= idx->g_n) RH_FAIL(RADHIP_E_RANGE, "node %u out of range (size %llu)", slot, (unsigned long long)idx->g_n);
+    if (level < 0 || level > idx->h_levels[slot])
+        RH_FAIL(RADHIP_E_RANGE, "node %u does not exist on level %d", slot, level);
+    const uint32_t w = level == 0 ? idx->cap0 : idx->M;
+    const uint32_t *row = level == 0 ? idx->h_adj0.data() + (uint64_t)slot * idx->cap0
+                                     : idx->h_adjU.data() + ((uint64_t)idx->h_upper_row[slot] + (level - 1)) * idx->M;
+    uint32_t k = 0;
+    for (uint32_t j = 0; j < w && row[j] != RADHIP_NO_SLOT; ++j) {
+        if (out_slots && k < cap) out_slots[k] = row[j];
+        ++k;
+    }
+    *out_n = k;
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_get_top_level_nodes(const radhip_index_t *cidx, uint32_t *out_slots, uint64_t cap,
+                                          uint64_t *out_n) {
+    radhip_index *idx = const_cast<radhip_index *>(cidx);
+    if (!idx || !out_n) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (!idx->has_graph) RH_FAIL(RADHIP_E_STATE, "no graph loaded");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    for (uint64_t i = 0; i < idx->h_top.size() && i < cap; ++i)
+        if (out_slots) out_slots[i] = idx->h_top[i];
+    *out_n = idx->h_top.size();
+    return RADHIP_OK;
+}
+
+// ------------------------------------------------------- K1: corpus scan --
+// One wave-load covers 64/LPR rows (1 KiB contiguous for 1024-bit rows): lane
+// l reads the 16-B chunk (l % LPR) of row (l / LPR).  NQ query chunks stay in
+// registers; and-counts are summed over the LPR lanes of a row with xor
+// shuffles; or = popc(query) + popc(row) - and.
+template <int LPR, int NQ>
+__global__ __launch_bounds__(256) void scan_kernel(const uint4 *__restrict__ fp, uint64_t first,
+                                                   uint64_t count, const uint4 *__restrict__ queries,
+                                                   const uint32_t *__restrict__ qpop,
+                                                   uint32_t *__restrict__ and_out,
+                                                   uint32_t *__restrict__ or_out) {
+    constexpr int RPB = 256 / LPR;  // rows per block pass
+    const int chunk = threadIdx.x % LPR;
+    const int rsub = threadIdx.x / LPR;
+    uint4 q[NQ];
+    uint32_t qp[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        q[i] = queries[i * LPR + chunk];
+        qp[i] = qpop[i];
+    }
+    const uint64_t n_groups = (count + RPB - 1) / RPB;
+    for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint64_t r = g * RPB + rsub;
+        const bool ok = r < count;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ok) v = fp[(first + r) * LPR + chunk];
+        const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v));
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const uint32_t a = rh_group_sum<LPR>(rh_popc4_and(v, q[i]));
+            if (ok && chunk == (i % LPR)) {
+                and_out[(uint64_t)i * count + r] = a;
+                or_out[(uint64_t)i * count + r] = qp[i] + rp - a;
+            }
+        }
+    }
+}
+
+template <int LPR>
+static int launch_scan(radhip_index *idx, int nq, uint64_t first, uint64_t count, const uint4 *dq,
+                       const uint32_t *dqpop, uint32_t *da, uint32_t *dorr) {
+    const uint64_t rpb = 256 / LPR;
+    uint64_t groups = (count + rpb - 1) / rpb;
+    uint32_t grid = (uint32_t)std::min<uint64_t>(groups, 256ull * 8ull);
+    if (grid == 0) grid = 1;
+#define RH_SCAN_CASE(NQV)                                                                       \
+    case NQV:                                                                                   \
+        hipLaunchKernelGGL((scan_kernel<LPR, NQV>), dim3(grid), dim3(256), 0, idx->stream, idx->d_fp, \
+                           first, count, dq, dqpop, da, dorr);                                  \
+        break;
+    switch (nq) {
+        RH_SCAN_CASE(1) RH_SCAN_CASE(2) RH_SCAN_CASE(3) RH_SCAN_CASE(4)
+        RH_SCAN_CASE(5) RH_SCAN_CASE(6) RH_SCAN_CASE(7) RH_SCAN_CASE(8)
+        default: RH_FAIL(RADHIP_E_INVALID, "internal: nq per pass must be 1..8");
+    }
+#undef RH_SCAN_CASE
+    RH_HIP(hipGetLastError());
+    return RADHIP_OK;
+}
+
+// pad host query rows to the device stride; also popcounts
+static void stage_queries(const radhip_index *idx, const uint8_t *queries, uint32_t nq,
+                          std::vector<uint8_t> &padded, std::vector<uint32_t> &pop) {
+    padded.assign((size_t)nq * idx->row_stride, 0);
+    pop.assign(nq, 0);
+    for (uint32_t i = 0; i < nq; ++i) {
+        memcpy(padded.data() + (size_t)i * idx->row_stride, queries + (size_t)i * idx->row_bytes, idx->row_bytes);
+        uint32_t p = 0;
+        for (uint32_t b = 0; b < idx->row_bytes; ++b) p += (uint32_t)__builtin_popcount(queries[(size_t)i * idx->row_bytes + b]);
+        pop[i] = p;
+    }
+}
+
+extern "C" int radhip_tanimoto_scan(radhip_index_t *idx, const uint8_t *queries, uint32_t nq,
+                                    uint64_t first, uint64_t count, uint32_t *and_out, uint32_t *or_out) {
+    if (!idx || !queries || !and_out || !or_out) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (!idx->has_vectors) RH_FAIL(RADHIP_E_STATE, "no vectors loaded");
+    if (first + count > idx->n) RH_FAIL(RADHIP_E_RANGE, "rows [first, first+count) out of range");
+    if (nq == 0 || count == 0) return RADHIP_OK;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_TRY(rh_ensure_device(idx));
+    std::vector<uint8_t> padded;
+    std::vector<uint32_t> pop;
+    stage_queries(idx, queries, nq, padded, pop);
+    uint4 *dq = nullptr;
+    uint32_t *dpop = nullptr, *da = nullptr, *dorr = nullptr;
+    const uint32_t pass = std::min<uint32_t>(nq, 8);
+    int rc = RADHIP_OK;
+    auto cleanup = [&]() { if (dq) (void)hipFree(dq); if (dpop) (void)hipFree(dpop); if (da) (void)hipFree(da); if (dorr) (void)hipFree(dorr); };
+#define RH_G(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { radhip_set_error("%s failed: %s", #x, hipGetErrorString(e_)); cleanup(); return RADHIP_E_HIP; } } while (0)
+    RH_G(hipMalloc((void **)&dq, padded.size()));
+    RH_G(hipMalloc((void **)&dpop, (size_t)nq * 4));
+    RH_G(hipMalloc((void **)&da, (size_t)pass * count * 4));
+    RH_G(hipMalloc((void **)&dorr, (size_t)pass * count * 4));
+    RH_G(hipMemcpyAsync(dq, padded.data(), padded.size(), hipMemcpyHostToDevice, idx->stream));
+    RH_G(hipMemcpyAsync(dpop, pop.data(), (size_t)nq * 4, hipMemcpyHostToDevice, idx->stream));
+    for (uint32_t q0 = 0; q0 < nq && rc == RADHIP_OK; q0 += pass) {
+        const int k = (int)std::min<uint32_t>(pass, nq - q0);
+        const uint4 *dqk = dq + (size_t)q0 * idx->lpr;
+        switch (idx->lpr) {
+            case 1: rc = launch_scan<1>(idx, k, first, count, dqk, dpop + q0, da, dorr); break;
+            case 2: rc = launch_scan<2>(idx, k, first, count, dqk, dpop + q0, da, dorr); break;
+            case 4: rc = launch_scan<4>(idx, k, first, count, dqk, dpop + q0, da, dorr); break;
+            case 8: rc = launch_scan<8>(idx, k, first, count, dqk, dpop + q0, da, dorr); break;
+            default: rc = launch_scan<16>(idx, k, first, count, dqk, dpop + q0, da, dorr); break;
+        }
+        if (rc != RADHIP_OK) break;
+        RH_G(hipMemcpyAsync(and_out + (size_t)q0 * count, da, (size_t)k * count * 4, hipMemcpyDeviceToHost, idx->stream));
+        RH_G(hipMemcpyAsync(or_out + (size_t)q0 * count, dorr, (size_t)k * count * 4, hipMemcpyDeviceToHost, idx->stream));
+        RH_G(hipStreamSynchronize(idx->stream));
+    }
+    cleanup();
+    return rc;
+}
+
+// ---------------------------------------------------- K2: gather-Tanimoto --
+// LPR lanes per (query, candidate) pair: random B-byte row gathers, 16 B per
+// lane, so a 1024-bit row is one 128-B line fetched by 8 adjacent lanes.
+template <int LPR>
+__global__ __launch_bounds__(256) void gather_kernel(const uint4 *__restrict__ fp,
+                                                     const uint4 *__restrict__ queries,
+                                                     const uint32_t *__restrict__ qpop,
+                                                     const uint32_t *__restrict__ pair_q,
+                                                     const uint32_t *__restrict__ pair_slot,
+                                                     uint64_t n_pairs, uint32_t *__restrict__ and_out,
+                                                     uint32_t *__restrict__ or_out) {
+    constexpr int PPB = 256 / LPR;
+    const int chunk = threadIdx.x % LPR;
+    const int psub = threadIdx.x / LPR;
+    const uint64_t n_groups = (n_pairs + PPB - 1) / PPB;
+    for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint64_t p = g * PPB + psub;
+        const bool ok = p < n_pairs;
+        uint4 v = make_uint4(0, 0, 0, 0), q = v;
+        uint32_t qi = 0;
+        if (ok) {
+            qi = pair_q[p];
+            v = fp[(uint64_t)pair_slot[p] * LPR + chunk];
+            q = queries[(uint64_t)qi * LPR + chunk];
+        }
+        const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v));
+        const uint32_t a = rh_group_sum<LPR>(rh_popc4_and(v, q));
+        if (ok && chunk == 0) {
+            and_out[p] = a;
+            or_out[p] = qpop[qi] + rp - a;
+        }
+    }
+}
+
+extern "C" int radhip_tanimoto_gather(radhip_index_t *idx, const uint8_t *queries, uint32_t nq,
+                                      const uint32_t *cand_slots, const uint64_t *cand_offsets,
+                                      uint32_t *and_out, uint32_t *or_out) {
+    if (!idx || !queries || !cand_offsets) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (!idx->has_vectors) RH_FAIL(RADHIP_E_STATE, "no vectors loaded");
+    const uint64_t n_pairs = nq ? cand_offsets[nq] : 0;
+    if (n_pairs == 0) return RADHIP_OK;
+    if (!cand_slots || !and_out || !or_out) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::vector<uint32_t> pq(n_pairs);
+    for (uint32_t q = 0; q < nq; ++q) {
+        if (cand_offsets[q + 1] < cand_offsets[q]) RH_FAIL(RADHIP_E_INVALID, "cand_offsets must be non-decreasing");
+        for (uint64_t i = cand_offsets[q]; i < cand_offsets[q + 1]; ++i) {
+            if (cand_slots[i] >= idx->n) RH_FAIL(RADHIP_E_RANGE, "candidate slot %u out of range", cand_slots[i]);
+            pq[i] = q;
+        }
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_TRY(rh_ensure_device(idx));
+    std::vector<uint8_t> padded;
+    std::vector<uint32_t> pop;
+    stage_queries(idx, queries, nq, padded, pop);
+    uint4 *dq = nullptr;
+    uint32_t *dpop = nullptr, *dpq = nullptr, *dps = nullptr, *da = nullptr, *dorr = nullptr;
+    auto cleanup = [&]() { if (dq) (void)hipFree(dq); if (dpop) (void)hipFree(dpop); if (dpq) (void)hipFree(dpq);
+                           if (dps) (void)hipFree(dps); if (da) (void)hipFree(da); if (dorr) (void)hipFree(dorr); };
+    RH_G(hipMalloc((void **)&dq, padded.size()));
+    RH_G(hipMalloc((void **)&dpop, (size_t)nq * 4));
+    RH_G(hipMalloc((void **)&dpq, n_pairs * 4));
+    RH_G(hipMalloc((void **)&dps, n_pairs * 4));
+    RH_G(hipMalloc((void **)&da, n_pairs * 4));
+    RH_G(hipMalloc((void **)&dorr, n_pairs * 4));
+    RH_G(hipMemcpyAsync(dq, padded.data(), padded.size(), hipMemcpyHostToDevice, idx->stream));
+    RH_G(hipMemcpyAsync(dpop, pop.data(), (size_t)nq * 4, hipMemcpyHostToDevice, idx->stream));
+    RH_G(hipMemcpyAsync(dpq, pq.data(), n_pairs * 4, hipMemcpyHostToDevice, idx->stream));
+    RH_G(hipMemcpyAsync(dps, cand_slots, n_pairs * 4, hipMemcpyHostToDevice, idx->stream));
+    const uint64_t ppb = 256 / idx->lpr;
+    uint32_t grid = (uint32_t)std::min<uint64_t>((n_pairs + ppb - 1) / ppb, 256ull * 16ull);
+    switch (idx->lpr) {
+        case 1: hipLaunchKernelGGL(gather_kernel<1>, dim3(grid), dim3(256), 0, idx->stream, idx->d_fp, dq, dpop, dpq, dps, n_pairs, da, dorr); break;
+        case 2: hipLaunchKernelGGL(gather_kernel<2>, dim3(grid), dim3(256), 0, idx->stream, idx->d_fp, dq, dpop, dpq, dps, n_pairs, da, dorr); break;
+        case 4: hipLaunchKernelGGL(gather_kernel<4>, dim3(grid), dim3(256), 0, idx->stream, idx->d_fp, dq, dpop, dpq, dps, n_pairs, da, dorr); break;
+        case 8: hipLaunchKernelGGL(gather_kernel<8>, dim3(grid), dim3(256), 0, idx->stream, idx->d_fp, dq, dpop, dpq, dps, n_pairs, da, dorr); break;
+        default: hipLaunchKernelGGL(gather_kernel<16>, dim3(grid), dim3(256), 0, idx->stream, idx->d_fp, dq, dpop, dpq, dps, n_pairs, da, dorr); break;
+    }
+    RH_G(hipGetLastError());
+    RH_G(hipMemcpyAsync(and_out, da, n_pairs * 4, hipMemcpyDeviceToHost, idx->stream));
+    RH_G(hipMemcpyAsync(or_out, dorr, n_pairs * 4, hipMemcpyDeviceToHost, idx->stream));
+    RH_G(hipStreamSynchronize(idx->stream));
+    cleanup();
+    return RADHIP_OK;
+#undef RH_G
+}

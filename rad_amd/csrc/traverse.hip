@@ -1,0 +1,613 @@
+// traverse.hip — K3: RAD best-first traversal, Tanimoto-scored, one wavefront
+// per traversal.  gfx950 only (wave64, LDS, no MFMA: this is bit counting).
+//
+// Reference control flow restated on the device (paths relative to the
+// reference tree):
+//   prime                 rad/traverser.py:141-170
+//   pop-min               rad/priority_queue.py:22-39   (ZSET order, see common.h key)
+//   neighbors             index.get_neighbors, rad/hnsw_service.py:222
+//   score-if-unscored     rad/distributed_worker.py:296-305
+//   visited test-and-set  rad/visited.py:17-29, key (node, level)
+//   scored insert         rad/scored.py:37-47, key node, insertion order
+//   queue insert/descend  rad/coordination_service.py:369-395
+//
+// Per-traversal state lives in HBM (sized for n_to_score):
+//   ht      open-addressing table {slot, and|or<<12|v0<<24}: presence == scored,
+//           v0 == visited on level 0
+//   ut      open-addressing set of (slot<<4|level)+1 for levels >= 1
+//   scored  {slot, and|or<<16} in insertion order (the output)
+//   pq      sorted runs of u64 keys, written once by staging flushes
+// and in LDS while the kernel runs:
+//   staging unsorted recent inserts (S_CAP keys), run heads (MAX_RUNS)
+#include "common.h"
+
+#include <algorithm>
+#include <new>
+
+#define S_CAP 1024u
+#define MAX_RUNS 256u
+#define HT_EMPTY 0xFFFFFFFFu
+#define VAL_V0 (1u << 24)
+
+struct TravHeader {
+    uint64_t n_scored, n_pops, n_nbr, pq_used, n_upper;
+    uint32_t stg_cnt, n_runs, qpop, primed;
+    int32_t status;
+    uint32_t pad;
+};
+
+struct TravParams {
+    const uint4 *fp;
+    const uint32_t *adj0, *upper_row, *adjU, *top;
+    uint32_t n_top, cap0, capU, nq;
+    int32_t start_level;
+    uint64_t n_to_score, max_pops;
+    TravHeader *hdr;
+    const uint4 *queries;
+    uint2 *ht;
+    uint32_t ht_log2;
+    unsigned long long *ut;
+    uint32_t ut_log2;
+    uint2 *scored;
+    uint64_t scored_cap;
+    unsigned long long *pq;
+    uint64_t pq_cap;
+    unsigned long long *stg_save;  // [nq * S_CAP]
+    uint2 *runs_save;              // [nq * MAX_RUNS] {pos, end}
+    uint32_t *poplog_nodes;
+    uint8_t *poplog_levels;
+    uint64_t poplog_cap;
+};
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        unsigned long long o = __shfl_xor(v, m, RH_WAVE);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_relaxed(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct TravLds {
+    unsigned long long stg[S_CAP];
+    unsigned long long rkey[MAX_RUNS];
+    uint32_t rpos[MAX_RUNS];
+    uint32_t rend[MAX_RUNS];
+    uint32_t new_slot[64];
+    uint32_t new_and[64];
+    uint32_t new_or[64];
+};
+
+// ascending in-place bitonic sort of s[0..P), P a power of two, by one wave
+__device__ void lds_bitonic_sort(unsigned long long *s, uint32_t P, uint32_t lane) {
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = lane; t < (P >> 1); t += 64) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t ixj = i | j;
+                const bool up = (i & k) == 0;
+                const unsigned long long a = s[i], b = s[ixj];
+                if ((a > b) == up) { s[i] = b; s[ixj] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
+    __shared__ TravLds L;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    TravHeader *H = P.hdr + q;
+    int32_t status = H->status;
+    if (status != 0) return;
+
+    uint64_t n_scored = H->n_scored, n_pops = H->n_pops, n_nbr = H->n_nbr, pq_used = H->pq_used,
+             n_upper = H->n_upper;
+    uint32_t cnt = H->stg_cnt, n_runs = H->n_runs;
+    const uint32_t qpop = H->qpop;
+    uint32_t primed = H->primed;
+
+    uint2 *ht = P.ht + ((uint64_t)q << P.ht_log2);
+    const uint32_t ht_shift = 32u - P.ht_log2;
+    const uint32_t ht_mask = (1u << P.ht_log2) - 1u;
+    unsigned long long *ut = P.ut + ((uint64_t)q << P.ut_log2);
+    const uint32_t ut_shift = 64u - P.ut_log2;
+    const uint32_t ut_mask = (1u << P.ut_log2) - 1u;
+    const uint64_t ut_limit = ((uint64_t)1 << P.ut_log2) - ((uint64_t)1 << P.ut_log2) / 4;
+    uint2 *scored = P.scored + (uint64_t)q * P.scored_cap;
+    unsigned long long *pq = P.pq + (uint64_t)q * P.pq_cap;
+    const uint32_t chunk = lane % LPR;
+    const uint4 qv = P.queries[(uint64_t)q * LPR + chunk];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    // ---- restore LDS state ------------------------------------------------
+    for (uint32_t i = lane; i < cnt; i += 64) L.stg[i] = P.stg_save[(uint64_t)q * S_CAP + i];
+    for (uint32_t r = lane; r < n_runs; r += 64) {
+        const uint2 pe = P.runs_save[(uint64_t)q * MAX_RUNS + r];
+        L.rpos[r] = pe.x;
+        L.rend[r] = pe.y;
+        L.rkey[r] = pe.x < pe.y ? pq[pe.x] : RH_KEY_INF;
+    }
+    __syncthreads();
+
+    // ---- flush staging into a new sorted run --------------------------------
+    auto flush = [&]() {
+        if (cnt == 0) return;
+        uint32_t Pw = 2;
+        while (Pw < cnt) Pw <<= 1;
+        for (uint32_t i = cnt + lane; i < Pw; i += 64) L.stg[i] = RH_KEY_INF;
+        __syncthreads();
+        lds_bitonic_sort(L.stg, Pw, lane);
+        // pick a run slot: reuse an exhausted one, else append
+        uint32_t r = n_runs;
+        for (uint32_t base = 0; base < n_runs; base += 64) {
+            const uint32_t i = base + lane;
+            const bool dead = i < n_runs && L.rkey[i] == RH_KEY_INF;
+            const unsigned long long b = __ballot(dead);
+            if (b) { r = base + (uint32_t)__ffsll((unsigned long long)b) - 1u; break; }
+        }
+        if ((r == n_runs && n_runs >= MAX_RUNS) || pq_used + cnt > P.pq_cap) {
+            status = RADHIP_E_CAPACITY;
+            return;
+        }
+        for (uint32_t i = lane; i < cnt; i += 64) pq[pq_used + i] = L.stg[i];
+        if (lane == 0) {
+            L.rpos[r] = (uint32_t)pq_used;
+            L.rend[r] = (uint32_t)(pq_used + cnt);
+            L.rkey[r] = L.stg[0];
+        }
+        if (r == n_runs) n_runs++;
+        pq_used += cnt;
+        cnt = 0;
+        __threadfence_block();
+        __syncthreads();
+    };
+
+    // ---- visited / scored / evaluate / enqueue for up to 64 candidate slots --
+    // (one per lane, distinct).  `prime` keeps the reference's unconditional
+    // queue insert of rad/traverser.py:158-168.
+    auto process = [&](uint32_t slot, bool valid, uint32_t level, bool prime) {
+        bool go = valid;
+        if (level > 0 && go) {
+            const unsigned long long k1 = (((unsigned long long)slot << 4) | level) + 1ull;
+            uint32_t h = (uint32_t)((k1 * 0x9E3779B97F4A7C15ull) >> ut_shift);
+            bool fresh = false;
+            for (;;) {
+                const unsigned long long old = atomicCAS(&ut[h], 0ull, k1);
+                if (old == 0ull) { fresh = true; break; }
+                if (old == k1) break;
+                h = (h + 1u) & ut_mask;
+            }
+            go = fresh || prime;
+        }
+        if (level > 0) {
+            // every lane that is still `go` inserted a fresh (slot, level) entry
+            n_upper += (uint64_t)__popcll(__ballot(go));
+            if (n_upper > ut_limit) { status = RADHIP_E_CAPACITY; return; }
+        }
+        bool isnew = false;
+        uint32_t h = 0;
+        if (go) {
+            h = (slot * 2654435769u) >> ht_shift;
+            for (;;) {
+                const uint32_t old = atomicCAS(&ht[h].x, HT_EMPTY, slot);
+                if (old == HT_EMPTY) { isnew = true; break; }
+                if (old == slot) break;
+                h = (h + 1u) & ht_mask;
+            }
+        }
+        uint32_t a = 0, o = 0;
+        bool push = false;
+        if (go && !isnew) {
+            const uint32_t val = ld_relaxed(&ht[h].y);
+            a = val & 0xFFFu;
+            o = (val >> 12) & 0xFFFu;
+            if (level == 0) {
+                if (!(val & VAL_V0) || prime) {
+                    st_relaxed(&ht[h].y, val | VAL_V0);
+                    push = true;
+                }
+            } else {
+                push = true;
+            }
+        }
+        const unsigned long long nb = __ballot(isnew);
+        const uint32_t nn = (uint32_t)__popcll(nb);
+        const uint32_t rank = (uint32_t)__popcll(nb & lt_mask);
+        if (nn) {
+            if (isnew) L.new_slot[rank] = slot;
+            __syncthreads();
+            constexpr uint32_t RPP = 64 / LPR;  // rows per pass
+            for (uint32_t base = 0; base < nn; base += RPP) {
+                const uint32_t ri = base + lane / LPR;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ri < nn) v = P.fp[(uint64_t)L.new_slot[ri] * LPR + chunk];
+                const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v));
+                const uint32_t aa = rh_group_sum<LPR>(rh_popc4_and(v, qv));
+                if (ri < nn && chunk == 0) {
+                    L.new_and[ri] = aa;
+                    L.new_or[ri] = qpop + rp - aa;
+                }
+            }
+            __syncthreads();
+            if (isnew) {
+                a = L.new_and[rank];
+                o = L.new_or[rank];
+                st_relaxed(&ht[h].y, a | (o << 12) | (level == 0 ? VAL_V0 : 0u));
+                scored[n_scored + rank] = make_uint2(slot, a | (o << 16));
+                push = true;
+            }
+            n_scored += nn;
+        }
+        // enqueue
+        const unsigned long long pb = __ballot(push);
+        if (pb) {
+            const uint32_t pr = (uint32_t)__popcll(pb & lt_mask);
+            if (push) L.stg[cnt + pr] = rh_make_key(rh_q24(a, o), slot, level);
+            cnt += (uint32_t)__popcll(pb);
+        }
+        __syncthreads();
+    };
+
+    // ---- prime ---------------------------------------------------------------
+    if (!primed) {
+        for (uint32_t base = 0; base < P.n_top && status == 0; base += 64) {
+            if (cnt + 65u > S_CAP) flush();
+            if (status) break;
+            const uint32_t i = base + lane;
+            const bool valid = i < P.n_top;
+            const uint32_t slot = valid ? P.top[i] : RADHIP_NO_SLOT;
+            process(slot, valid, (uint32_t)P.start_level, true);
+        }
+        primed = 1;
+    }
+
+    // ---- best-first loop -------------------------------------------------------
+    uint64_t pops_here = 0;
+    while (status == 0) {
+        if (n_scored >= P.n_to_score) { status = 1; break; }
+        if (P.max_pops && pops_here >= P.max_pops) break;
+        if (cnt + 66u > S_CAP) { flush(); if (status) break; }
+        // pop-min over staging and run heads
+        unsigned long long best = RH_KEY_INF;
+        uint32_t src = 0;
+        for (uint32_t i = lane; i < cnt; i += 64) {
+            const unsigned long long k = L.stg[i];
+            if (k < best) { best = k; src = i; }
+        }
+        for (uint32_t r = lane; r < n_runs; r += 64) {
+            const unsigned long long k = L.rkey[r];
+            if (k < best) { best = k; src = 0x80000000u | r; }
+        }
+        const unsigned long long mk = wave_min_u64(best);
+        if (mk == RH_KEY_INF) { status = 2; break; }
+        const unsigned long long wb = __ballot(best == mk);
+        const int win = __ffsll((unsigned long long)wb) - 1;
+        const uint32_t wsrc = __shfl(src, win, RH_WAVE);
+        if (wsrc & 0x80000000u) {
+            const uint32_t r = wsrc & 0x7FFFFFFFu;
+            if (lane == 0) {
+                const uint32_t pos = L.rpos[r] + 1u;
+                L.rpos[r] = pos;
+                L.rkey[r] = pos < L.rend[r] ? pq[pos] : RH_KEY_INF;
+            }
+        } else {
+            if (lane == 0) L.stg[wsrc] = L.stg[cnt - 1u];
+            cnt--;
+        }
+        __syncthreads();
+        uint32_t node, level;
+        rh_decode_key(mk, &node, &level);
+        if (P.poplog_nodes && n_pops < P.poplog_cap && lane == 0) {
+            P.poplog_nodes[(uint64_t)q * P.poplog_cap + n_pops] = node;
+            P.poplog_levels[(uint64_t)q * P.poplog_cap + n_pops] = (uint8_t)level;
+        }
+        n_pops++;
+        pops_here++;
+        // adjacency row
+        uint32_t nbr = RADHIP_NO_SLOT;
+        if (level == 0) {
+            if (lane < P.cap0) nbr = P.adj0[(uint64_t)node * P.cap0 + lane];
+        } else {
+            const uint32_t ur = P.upper_row[node];
+            if (lane < P.capU) nbr = P.adjU[((uint64_t)ur + (level - 1u)) * P.capU + lane];
+        }
+        const bool valid = nbr != RADHIP_NO_SLOT;
+        n_nbr += (uint64_t)__popcll(__ballot(valid));
+        process(nbr, valid, level, false);
+        if (status) break;
+        // descend: same node, one level down, same score
+        if (level > 0) {
+            const uint32_t nl = level - 1u;
+            bool push0 = false;
+            if (lane == 0) {
+                if (nl > 0) {
+                    const unsigned long long k1 = (((unsigned long long)node << 4) | nl) + 1ull;
+                    uint32_t h = (uint32_t)((k1 * 0x9E3779B97F4A7C15ull) >> ut_shift);
+                    for (;;) {
+                        const unsigned long long old = atomicCAS(&ut[h], 0ull, k1);
+                        if (old == 0ull) { push0 = true; break; }
+                        if (old == k1) break;
+                        h = (h + 1u) & ut_mask;
+                    }
+                } else {
+                    uint32_t h = (node * 2654435769u) >> ht_shift;
+                    for (;;) {  // node is scored, hence present
+                        const uint32_t old = ld_relaxed(&ht[h].x);
+                        if (old == node) break;
+                        if (old == HT_EMPTY) break;  // unreachable by construction
+                        h = (h + 1u) & ht_mask;
+                    }
+                    const uint32_t val = ld_relaxed(&ht[h].y);
+                    if (!(val & VAL_V0)) { st_relaxed(&ht[h].y, val | VAL_V0); push0 = true; }
+                }
+                if (push0) {
+                    const uint64_t qbits = mk >> 38;
+                    L.stg[cnt] = rh_make_key((uint32_t)qbits, node, nl);
+                }
+            }
+            const bool p0 = __shfl((int)push0, 0, RH_WAVE) != 0;
+            if (p0) {
+                cnt++;
+                if (nl > 0) n_upper++;
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- persist ---------------------------------------------------------------
+    for (uint32_t i = lane; i < cnt; i += 64) P.stg_save[(uint64_t)q * S_CAP + i] = L.stg[i];
+    for (uint32_t r = lane; r < n_runs; r += 64)
+        P.runs_save[(uint64_t)q * MAX_RUNS + r] = make_uint2(L.rpos[r], L.rend[r]);
+    if (lane == 0) {
+        H->n_scored = n_scored; H->n_pops = n_pops; H->n_nbr = n_nbr; H->pq_used = pq_used;
+        H->n_upper = n_upper; H->stg_cnt = cnt; H->n_runs = n_runs; H->primed = primed;
+        H->status = status;
+    }
+}
+
+// ================================================================== host side
+struct radhip_traversal {
+    radhip_index *idx = nullptr;
+    uint32_t nq = 0;
+    uint64_t n_to_score = 0;
+    uint32_t flags = 0;
+    TravParams P{};
+    uint4 *d_queries = nullptr;
+    size_t ht_bytes = 0, ut_bytes = 0, scored_bytes = 0, pq_bytes = 0, stg_bytes = 0, runs_bytes = 0,
+           hdr_bytes = 0, log_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double kernel_ms = 0.0;
+    uint64_t launches = 0;
+    uint64_t state_bytes = 0;
+};
+
+static uint32_t log2_ceil(uint64_t x) {
+    uint32_t l = 0;
+    while (((uint64_t)1 << l) < x) l++;
+    return l;
+}
+
+static int trav_upload_queries(radhip_traversal *t, const uint8_t *queries) {
+    radhip_index *idx = t->idx;
+    std::vector<uint8_t> padded((size_t)t->nq * idx->row_stride, 0);
+    std::vector<TravHeader> hdr(t->nq);
+    memset(hdr.data(), 0, hdr.size() * sizeof(TravHeader));
+    for (uint32_t i = 0; i < t->nq; ++i) {
+        memcpy(padded.data() + (size_t)i * idx->row_stride, queries + (size_t)i * idx->row_bytes, idx->row_bytes);
+        uint32_t p = 0;
+        for (uint32_t b = 0; b < idx->row_bytes; ++b) p += (uint32_t)__builtin_popcount(queries[(size_t)i * idx->row_bytes + b]);
+        hdr[i].qpop = p;
+    }
+    RH_HIP(hipMemcpyAsync(t->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, idx->stream));
+    RH_HIP(hipMemcpyAsync(t->P.hdr, hdr.data(), t->hdr_bytes, hipMemcpyHostToDevice, idx->stream));
+    RH_HIP(hipMemsetAsync(t->P.ht, 0xFF, t->ht_bytes, idx->stream));
+    RH_HIP(hipMemsetAsync(t->P.ut, 0x00, t->ut_bytes, idx->stream));
+    RH_HIP(hipStreamSynchronize(idx->stream));
+    t->kernel_ms = 0.0;
+    t->launches = 0;
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_traversal_destroy(radhip_traversal_t *t) {
+    if (!t) return RADHIP_OK;
+    if (t->idx && t->idx->dev_ready) (void)hipSetDevice(t->idx->device);
+    if (t->d_queries) (void)hipFree(t->d_queries);
+    if (t->P.hdr) (void)hipFree(t->P.hdr);
+    if (t->P.ht) (void)hipFree(t->P.ht);
+    if (t->P.ut) (void)hipFree(t->P.ut);
+    if (t->P.scored) (void)hipFree(t->P.scored);
+    if (t->P.pq) (void)hipFree(t->P.pq);
+    if (t->P.stg_save) (void)hipFree(t->P.stg_save);
+    if (t->P.runs_save) (void)hipFree(t->P.runs_save);
+    if (t->P.poplog_nodes) (void)hipFree(t->P.poplog_nodes);
+    if (t->P.poplog_levels) (void)hipFree(t->P.poplog_levels);
+    if (t->ev0) (void)hipEventDestroy(t->ev0);
+    if (t->ev1) (void)hipEventDestroy(t->ev1);
+    delete t;
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queries, uint32_t nq,
+                                       uint64_t n_to_score, uint32_t flags, radhip_traversal_t **out) {
+    if (!idx || !queries || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (nq == 0) RH_FAIL(RADHIP_E_INVALID, "nq must be > 0");
+    if (n_to_score == 0) RH_FAIL(RADHIP_E_INVALID, "n_to_score must be > 0");
+    if (!idx->has_vectors || !idx->has_graph) RH_FAIL(RADHIP_E_STATE, "index needs vectors and a graph");
+    if (idx->g_n > idx->n) RH_FAIL(RADHIP_E_STATE, "graph has more nodes (%llu) than the corpus has rows (%llu)",
+                                   (unsigned long long)idx->g_n, (unsigned long long)idx->n);
+    if (idx->g_n > 1000000000ull) RH_FAIL(RADHIP_E_INVALID, "RAD traversal needs slots < 1e9");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_TRY(rh_ensure_device(idx));
+    radhip_traversal *t = new (std::nothrow) radhip_traversal();
+    if (!t) RH_FAIL(RADHIP_E_NOMEM, "out of host memory");
+    t->idx = idx; t->nq = nq; t->n_to_score = n_to_score; t->flags = flags;
+    const uint64_t n_top = idx->n_top;
+    if (n_to_score > idx->g_n) n_to_score = idx->g_n;  // cannot score more than exist
+    t->n_to_score = n_to_score;
+    const uint64_t scored_cap = n_to_score + 64 + n_top;
+    const uint32_t ht_log2 = std::max<uint32_t>(10, log2_ceil(2 * scored_cap));
+    const uint64_t up_pairs = idx->n_upper_rows + n_top * (uint64_t)(idx->max_level + 1);
+    uint64_t ut_need = std::min<uint64_t>(2 * up_pairs + 64, scored_cap * 8 / idx->M + 1024);
+    const uint32_t ut_log2 = std::max<uint32_t>(10, log2_ceil(ut_need));
+    if (ht_log2 > 31 || ut_log2 > 31) { delete t; RH_FAIL(RADHIP_E_INVALID, "n_to_score too large"); }
+    const uint64_t pq_cap = scored_cap + ((uint64_t)1 << ut_log2);
+    if (pq_cap >= 0xFFFFFFFFull) { delete t; RH_FAIL(RADHIP_E_INVALID, "n_to_score too large"); }
+    TravParams &P = t->P;
+    P.fp = idx->d_fp; P.adj0 = idx->d_adj0; P.upper_row = idx->d_upper_row; P.adjU = idx->d_adjU;
+    P.top = idx->d_top; P.n_top = idx->n_top; P.cap0 = idx->cap0; P.capU = idx->M; P.nq = nq;
+    P.start_level = idx->max_level > 0 ? idx->max_level - 1 : 0;
+    P.n_to_score = n_to_score; P.max_pops = 0;
+    P.ht_log2 = ht_log2; P.ut_log2 = ut_log2; P.scored_cap = scored_cap; P.pq_cap = pq_cap;
+    t->hdr_bytes = (size_t)nq * sizeof(TravHeader);
+    t->ht_bytes = ((size_t)nq << ht_log2) * sizeof(uint2);
+    t->ut_bytes = ((size_t)nq << ut_log2) * 8;
+    t->scored_bytes = (size_t)nq * scored_cap * sizeof(uint2);
+    t->pq_bytes = (size_t)nq * pq_cap * 8;
+    t->stg_bytes = (size_t)nq * S_CAP * 8;
+    t->runs_bytes = (size_t)nq * MAX_RUNS * sizeof(uint2);
+    int rc = RADHIP_OK;
+#define RH_A(ptr, bytes)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 16);                \
+        if (e_ != hipSuccess) {                                                            \
+            radhip_set_error("hipMalloc(%zu) for traversal state failed: %s", (size_t)(bytes), hipGetErrorString(e_)); \
+            rc = e_ == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP;                \
+        } else t->state_bytes += (bytes);                                                  \
+    } while (0)
+    RH_A(t->d_queries, (size_t)nq * idx->row_stride);
+    if (rc == 0) RH_A(P.hdr, t->hdr_bytes);
+    if (rc == 0) RH_A(P.ht, t->ht_bytes);
+    if (rc == 0) RH_A(P.ut, t->ut_bytes);
+    if (rc == 0) RH_A(P.scored, t->scored_bytes);
+    if (rc == 0) RH_A(P.pq, t->pq_bytes);
+    if (rc == 0) RH_A(P.stg_save, t->stg_bytes);
+    if (rc == 0) RH_A(P.runs_save, t->runs_bytes);
+    if (rc == 0 && (flags & RADHIP_TRAV_LOG_POPS)) {
+        P.poplog_cap = pq_cap;
+        RH_A(P.poplog_nodes, (size_t)nq * P.poplog_cap * 4);
+        if (rc == 0) RH_A(P.poplog_levels, (size_t)nq * P.poplog_cap);
+    }
+#undef RH_A
+    if (rc == 0 && hipEventCreate(&t->ev0) != hipSuccess) rc = RADHIP_E_HIP;
+    if (rc == 0 && hipEventCreate(&t->ev1) != hipSuccess) rc = RADHIP_E_HIP;
+    if (rc != 0) { radhip_traversal_destroy(t); return rc; }
+    P.queries = t->d_queries;
+    rc = trav_upload_queries(t, queries);
+    if (rc != 0) { radhip_traversal_destroy(t); return rc; }
+    *out = t;
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_traversal_reset(radhip_traversal_t *t, const uint8_t *queries) {
+    if (!t || !queries) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(t->idx->mu);
+    RH_HIP(hipSetDevice(t->idx->device));
+    return trav_upload_queries(t, queries);
+}
+
+extern "C" int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, uint32_t *out_running) {
+    if (!t) RH_FAIL(RADHIP_E_INVALID, "null traversal");
+    radhip_index *idx = t->idx;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_HIP(hipSetDevice(idx->device));
+    // the graph may have been re-uploaded since create
+    t->P.fp = idx->d_fp; t->P.adj0 = idx->d_adj0; t->P.upper_row = idx->d_upper_row;
+    t->P.adjU = idx->d_adjU; t->P.top = idx->d_top;
+    t->P.max_pops = max_pops;
+    RH_HIP(hipEventRecord(t->ev0, idx->stream));
+    switch (idx->lpr) {
+        case 1: hipLaunchKernelGGL(trav_kernel<1>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
+        case 2: hipLaunchKernelGGL(trav_kernel<2>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
+        case 4: hipLaunchKernelGGL(trav_kernel<4>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
+        case 8: hipLaunchKernelGGL(trav_kernel<8>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
+        default: hipLaunchKernelGGL(trav_kernel<16>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
+    }
+    RH_HIP(hipGetLastError());
+    RH_HIP(hipEventRecord(t->ev1, idx->stream));
+    RH_HIP(hipStreamSynchronize(idx->stream));
+    float ms = 0.f;
+    RH_HIP(hipEventElapsedTime(&ms, t->ev0, t->ev1));
+    t->kernel_ms += ms;
+    t->launches++;
+    std::vector<TravHeader> hdr(t->nq);
+    RH_HIP(hipMemcpy(hdr.data(), t->P.hdr, t->hdr_bytes, hipMemcpyDeviceToHost));
+    uint32_t running = 0;
+    int bad = 0;
+    for (uint32_t i = 0; i < t->nq; ++i) {
+        if (hdr[i].status == 0) running++;
+        if (hdr[i].status < 0 && !bad) bad = hdr[i].status;
+    }
+    if (out_running) *out_running = running;
+    if (bad) RH_FAIL(bad, "traversal state overflowed a fixed-capacity device structure (status %d)", bad);
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_traversal_stats(const radhip_traversal_t *t, radhip_trav_stats_t *out) {
+    if (!t || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(t->idx->mu);
+    RH_HIP(hipSetDevice(t->idx->device));
+    std::vector<TravHeader> hdr(t->nq);
+    RH_HIP(hipMemcpy(hdr.data(), t->P.hdr, t->hdr_bytes, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < t->nq; ++i) {
+        out[i].n_scored = hdr[i].n_scored; out[i].n_pops = hdr[i].n_pops; out[i].n_nbr = hdr[i].n_nbr;
+        out[i].status = hdr[i].status; out[i].reserved = 0;
+    }
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_traversal_results(const radhip_traversal_t *t, uint32_t q, uint32_t *out_slots,
+                                        uint32_t *out_and, uint32_t *out_or, uint64_t cap, uint64_t *out_n) {
+    if (!t || !out_n) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (q >= t->nq) RH_FAIL(RADHIP_E_RANGE, "traversal %u out of range", q);
+    std::lock_guard<std::mutex> lk(t->idx->mu);
+    RH_HIP(hipSetDevice(t->idx->device));
+    TravHeader h;
+    RH_HIP(hipMemcpy(&h, t->P.hdr + q, sizeof h, hipMemcpyDeviceToHost));
+    const uint64_t n = std::min<uint64_t>(h.n_scored, cap);
+    *out_n = h.n_scored;
+    if (n == 0) return RADHIP_OK;
+    std::vector<uint2> buf(n);
+    RH_HIP(hipMemcpy(buf.data(), t->P.scored + (uint64_t)q * t->P.scored_cap, n * sizeof(uint2), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) {
+        if (out_slots) out_slots[i] = buf[i].x;
+        if (out_and) out_and[i] = buf[i].y & 0xFFFFu;
+        if (out_or) out_or[i] = buf[i].y >> 16;
+    }
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_traversal_pop_log(const radhip_traversal_t *t, uint32_t q, uint32_t *out_nodes,
+                                        uint8_t *out_levels, uint64_t cap, uint64_t *out_n) {
+    if (!t || !out_n) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (q >= t->nq) RH_FAIL(RADHIP_E_RANGE, "traversal %u out of range", q);
+    if (!t->P.poplog_nodes) RH_FAIL(RADHIP_E_STATE, "traversal was created without RADHIP_TRAV_LOG_POPS");
+    std::lock_guard<std::mutex> lk(t->idx->mu);
+    RH_HIP(hipSetDevice(t->idx->device));
+    TravHeader h;
+    RH_HIP(hipMemcpy(&h, t->P.hdr + q, sizeof h, hipMemcpyDeviceToHost));
+    const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(h.n_pops, t->P.poplog_cap), cap);
+    *out_n = std::min<uint64_t>(h.n_pops, t->P.poplog_cap);
+    if (n == 0) return RADHIP_OK;
+    if (out_nodes) RH_HIP(hipMemcpy(out_nodes, t->P.poplog_nodes + (uint64_t)q * t->P.poplog_cap, n * 4, hipMemcpyDeviceToHost));
+    if (out_levels) RH_HIP(hipMemcpy(out_levels, t->P.poplog_levels + (uint64_t)q * t->P.poplog_cap, n, hipMemcpyDeviceToHost));
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_traversal_kernel_time(const radhip_traversal_t *t, double *out_ms, uint64_t *out_launches) {
+    if (!t) RH_FAIL(RADHIP_E_INVALID, "null traversal");
+    if (out_ms) *out_ms = t->kernel_ms;
+    if (out_launches) *out_launches = t->launches;
+    return RADHIP_OK;
+}
+
+extern "C" uint64_t radhip_traversal_state_bytes(const radhip_traversal_t *t) { return t ? t->state_bytes : 0; }

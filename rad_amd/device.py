@@ -1,0 +1,216 @@
+"""Thin object wrappers over the librad_hip C ABI: DeviceIndex and DeviceTraversal.
+
+These hold opaque C handles; all arithmetic of the hot path happens in the HIP
+kernels behind them (rad_amd/csrc).  numpy is used only to own host buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import NO_SLOT, RadHipError, check, ptr
+
+
+def distance_f32(and_cnt, or_cnt) -> np.ndarray:
+    """Float edge value of the integer counts: 1.0f - (float)and/(float)or in
+    float32 (one division, one subtraction), 0.0 when or == 0."""
+    a = np.asarray(and_cnt, dtype=np.float32)
+    o = np.asarray(or_cnt, dtype=np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = np.divide(a, o, dtype=np.float32)
+        d = np.subtract(np.float32(1.0), q, dtype=np.float32)
+    return np.where(np.asarray(or_cnt) == 0, np.float32(0.0), d).astype(np.float32)
+
+
+class DeviceIndex:
+    """Corpus + layered adjacency resident in HBM (radhip_index_t)."""
+
+    def __init__(self, ndim: int, connectivity: int, connectivity_base: int = 0,
+                 expansion_add: int = 128, device: int = 0):
+        self._h = C.c_void_p()
+        self._L = _lib.lib()
+        check(self._L.radhip_index_create(ndim, connectivity, connectivity_base, expansion_add,
+                                          device, C.byref(self._h)))
+        self.row_bytes = (ndim + 7) // 8
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.radhip_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- metadata ---------------------------------------------------------
+    def info(self) -> _lib.IndexInfo:
+        out = _lib.IndexInfo()
+        check(self._L.radhip_index_info(self._h, C.byref(out)))
+        return out
+
+    # -- corpus -----------------------------------------------------------
+    def load_vectors(self, rows: np.ndarray) -> None:
+        rows = _lib.as_rows(rows, self.row_bytes)
+        check(self._L.radhip_index_load_vectors(self._h, ptr(rows), rows.shape[0]))
+
+    def synth_vectors(self, n: int, seed: int, mode: int = 1, first_row: int = 0,
+                      n_total: Optional[int] = None) -> None:
+        check(self._L.radhip_index_synth_vectors(self._h, n, first_row,
+                                                 n if n_total is None else n_total, seed, mode))
+
+    def read_vectors(self, first: int, count: int) -> np.ndarray:
+        out = np.empty((count, self.row_bytes), np.uint8)
+        check(self._L.radhip_index_read_vectors(self._h, first, count, ptr(out)))
+        return out
+
+    # -- graph ------------------------------------------------------------
+    def load_graph(self, levels, adj0, upper_row, adjU, max_level: int, entry: int) -> None:
+        inf = self.info()
+        levels = np.ascontiguousarray(levels, np.int8)
+        n = levels.shape[0]
+        adj0 = np.ascontiguousarray(adj0, np.uint32).reshape(n, inf.connectivity_base)
+        upper_row = np.ascontiguousarray(upper_row, np.uint32).reshape(n)
+        adjU = np.ascontiguousarray(adjU, np.uint32).reshape(-1, inf.connectivity)
+        check(self._L.radhip_index_load_graph(self._h, n, max_level, entry, ptr(levels), ptr(adj0),
+                                              ptr(upper_row), ptr(adjU), adjU.shape[0]))
+
+    def synth_graph(self, seed: int) -> None:
+        check(self._L.radhip_index_synth_graph(self._h, seed))
+
+    def read_graph(self):
+        inf = self.info()
+        n = inf.n
+        levels = np.empty(n, np.int8)
+        adj0 = np.empty((n, inf.connectivity_base), np.uint32)
+        upper_row = np.empty(n, np.uint32)
+        adjU = np.empty((inf.n_upper_rows, inf.connectivity), np.uint32)
+        check(self._L.radhip_index_read_graph(self._h, ptr(levels), ptr(adj0), ptr(upper_row), ptr(adjU)))
+        return levels, adj0, upper_row, adjU
+
+    def get_neighbors(self, slot: int, level: int) -> np.ndarray:
+        out = np.empty(64, np.uint32)
+        n = C.c_uint32(0)
+        check(self._L.radhip_get_neighbors(self._h, slot, level, ptr(out), 64, C.byref(n)))
+        return out[: n.value].copy()
+
+    def get_top_level_nodes(self) -> np.ndarray:
+        n = C.c_uint64(0)
+        check(self._L.radhip_get_top_level_nodes(self._h, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.uint32)
+        check(self._L.radhip_get_top_level_nodes(self._h, ptr(out), n.value, C.byref(n)))
+        return out
+
+    # -- Tanimoto kernels ---------------------------------------------------
+    def scan(self, queries: np.ndarray, first: int = 0, count: Optional[int] = None):
+        """K1: (and, or) of every query against rows [first, first+count)."""
+        q = _lib.as_rows(queries, self.row_bytes, "queries")
+        if count is None:
+            count = self.info().n - first
+        a = np.empty((q.shape[0], count), np.uint32)
+        o = np.empty((q.shape[0], count), np.uint32)
+        check(self._L.radhip_tanimoto_scan(self._h, ptr(q), q.shape[0], first, count, ptr(a), ptr(o)))
+        return a, o
+
+    def gather(self, queries: np.ndarray, cand_slots: np.ndarray, cand_offsets: np.ndarray):
+        """K2: (and, or) of query i against cand_slots[cand_offsets[i]:cand_offsets[i+1]]."""
+        q = _lib.as_rows(queries, self.row_bytes, "queries")
+        s = np.ascontiguousarray(cand_slots, np.uint32)
+        off = np.ascontiguousarray(cand_offsets, np.uint64)
+        if off.shape[0] != q.shape[0] + 1 or int(off[-1]) != s.shape[0]:
+            raise ValueError("cand_offsets must have nq+1 entries ending at len(cand_slots)")
+        a = np.empty(s.shape[0], np.uint32)
+        o = np.empty(s.shape[0], np.uint32)
+        check(self._L.radhip_tanimoto_gather(self._h, ptr(q), q.shape[0], ptr(s), ptr(off), ptr(a), ptr(o)))
+        return a, o
+
+
+@dataclass
+class TraversalStats:
+    n_scored: np.ndarray
+    n_pops: np.ndarray
+    n_nbr: np.ndarray
+    status: np.ndarray
+
+
+class DeviceTraversal:
+    """nq independent RAD traversals, Tanimoto-scored, state in HBM (radhip_traversal_t)."""
+
+    def __init__(self, index: DeviceIndex, queries: np.ndarray, n_to_score: int, log_pops: bool = False):
+        self._L = _lib.lib()
+        self.index = index
+        q = _lib.as_rows(queries, index.row_bytes, "queries")
+        self.nq = q.shape[0]
+        self.n_to_score = int(n_to_score)
+        self._h = C.c_void_p()
+        check(self._L.radhip_traversal_create(index._h, ptr(q), self.nq, self.n_to_score,
+                                              _lib.TRAV_LOG_POPS if log_pops else 0, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.radhip_traversal_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, queries: np.ndarray) -> None:
+        q = _lib.as_rows(queries, self.index.row_bytes, "queries")
+        if q.shape[0] != self.nq:
+            raise ValueError(f"reset needs exactly {self.nq} queries")
+        check(self._L.radhip_traversal_reset(self._h, ptr(q)))
+
+    def run(self, max_pops: int = 0) -> int:
+        """Advance every unfinished traversal by at most max_pops expansions
+        (0 = to completion); returns how many are still running."""
+        running = C.c_uint32(0)
+        check(self._L.radhip_traversal_run(self._h, max_pops, C.byref(running)))
+        return running.value
+
+    def stats(self) -> TraversalStats:
+        arr = (_lib.TravStats * self.nq)()
+        check(self._L.radhip_traversal_stats(self._h, arr))
+        return TraversalStats(np.array([s.n_scored for s in arr], np.int64),
+                              np.array([s.n_pops for s in arr], np.int64),
+                              np.array([s.n_nbr for s in arr], np.int64),
+                              np.array([s.status for s in arr], np.int32))
+
+    def results(self, q: int):
+        """(slots, and, or) of traversal q in traversal order."""
+        n = C.c_uint64(0)
+        check(self._L.radhip_traversal_results(self._h, q, None, None, None, 0, C.byref(n)))
+        k = n.value
+        s = np.empty(k, np.uint32)
+        a = np.empty(k, np.uint32)
+        o = np.empty(k, np.uint32)
+        check(self._L.radhip_traversal_results(self._h, q, ptr(s), ptr(a), ptr(o), k, C.byref(n)))
+        return s, a, o
+
+    def pop_log(self, q: int):
+        n = C.c_uint64(0)
+        check(self._L.radhip_traversal_pop_log(self._h, q, None, None, 0, C.byref(n)))
+        k = n.value
+        nodes = np.empty(k, np.uint32)
+        levels = np.empty(k, np.uint8)
+        check(self._L.radhip_traversal_pop_log(self._h, q, ptr(nodes), ptr(levels), k, C.byref(n)))
+        return nodes, levels
+
+    def kernel_time(self):
+        ms = C.c_double(0)
+        n = C.c_uint64(0)
+        check(self._L.radhip_traversal_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def state_bytes(self) -> int:
+        return int(self._L.radhip_traversal_state_bytes(self._h))
+
+
+__all__ = ["DeviceIndex", "DeviceTraversal", "TraversalStats", "distance_f32", "NO_SLOT", "RadHipError"]

@@ -1,0 +1,161 @@
+"""GPU parity tests (through the C ABI) of K1 scan, K2 gather, the synthetic
+generators and the K3 RAD traversal against the CPU oracle.  Bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk_index(ndim, M, cap0=0):
+    from rad_amd.device import DeviceIndex
+    return DeviceIndex(ndim, M, cap0, 64)
+
+
+@pytest.mark.parametrize("ndim,mode", [(1024, 1), (1024, 0), (2048, 1), (64, 0), (512, 1), (100, 0)])
+def test_synth_rows_match_oracle(gpu, oracle, ndim, mode):
+    idx = _mk_index(ndim, 8)
+    n = 5000
+    idx.synth_vectors(n, seed=11, mode=mode)
+    got = idx.read_vectors(0, n)
+    want = oracle.synth_rows(0, n, n, ndim, 11, mode)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n,M,cap0", [(4096, 8, 16), (20000, 8, 16), (3000, 4, 8), (50000, 16, 32), (70000, 32, 64)])
+def test_synth_graph_matches_oracle(gpu, oracle, n, M, cap0):
+    idx = _mk_index(1024, M, cap0)
+    idx.synth_vectors(n, seed=5, mode=1)
+    idx.synth_graph(seed=9)
+    levels, adj0, upper_row, adjU = idx.read_graph()
+    g = oracle.synth_graph(n, M, cap0, 9)
+    assert idx.info().max_level == g.max_level
+    assert np.array_equal(levels, g.levels)
+    assert np.array_equal(adj0, g.adj0)
+    assert np.array_equal(upper_row, g.upper_row)
+    assert np.array_equal(adjU, g.adjU)
+    assert np.array_equal(idx.get_top_level_nodes(), g.top_level())
+
+
+@pytest.mark.parametrize("ndim", [64, 256, 1024, 2048, 1000])
+@pytest.mark.parametrize("nq", [1, 3, 8, 11])
+def test_scan_matches_oracle(gpu, oracle, ndim, nq):
+    rng = np.random.default_rng(ndim + nq)
+    n = 3001
+    rb = (ndim + 7) // 8
+    X = rng.integers(0, 256, (n, rb), dtype=np.uint8)
+    if ndim % 8:
+        X[:, -1] &= (1 << (ndim % 8)) - 1
+    X[7] = 0  # all-zero row: or may be 0 against an all-zero query
+    Q = X[rng.integers(0, n, nq)].copy()
+    Q[0] = 0
+    idx = _mk_index(ndim, 8)
+    idx.load_vectors(X)
+    a, o = idx.scan(Q)
+    for i in range(nq):
+        wa, wo = oracle.scan(X, Q[i])
+        assert np.array_equal(a[i], wa) and np.array_equal(o[i], wo)
+    # sub-range
+    a2, o2 = idx.scan(Q[:2], first=100, count=777)
+    assert np.array_equal(a2, a[:2, 100:877]) and np.array_equal(o2, o[:2, 100:877])
+
+
+@pytest.mark.parametrize("ndim", [64, 1024, 2048])
+def test_gather_matches_oracle(gpu, oracle, ndim):
+    rng = np.random.default_rng(ndim)
+    n, nq = 4000, 5
+    X = rng.integers(0, 256, (n, (ndim + 7) // 8), dtype=np.uint8)
+    Q = X[:nq]
+    sizes = [0, 1, 17, 256, 1000]
+    slots = np.concatenate([rng.integers(0, n, s) for s in sizes]).astype(np.uint32)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    idx = _mk_index(ndim, 8)
+    idx.load_vectors(X)
+    a, o = idx.gather(Q, slots, off)
+    for i in range(nq):
+        wa, wo = oracle.gather(X, Q[i], slots[int(off[i]):int(off[i + 1])])
+        assert np.array_equal(a[int(off[i]):int(off[i + 1])], wa)
+        assert np.array_equal(o[int(off[i]):int(off[i + 1])], wo)
+
+
+def _check_traversal(oracle, idx, graph, X, Q, n_to_score):
+    from rad_amd.device import DeviceTraversal
+    t = DeviceTraversal(idx, Q, n_to_score, log_pops=True)
+    assert t.run() == 0
+    st = t.stats()
+    for i in range(Q.shape[0]):
+        want = oracle.rad_traverse(graph, X, Q[i], n_to_score)
+        s, a, o = t.results(i)
+        nodes, levels = t.pop_log(i)
+        assert st.n_pops[i] == want.n_pops, (i, st.n_pops[i], want.n_pops)
+        assert np.array_equal(nodes, want.pop_nodes), f"traversal {i}: expansion order differs"
+        assert np.array_equal(levels, want.pop_levels)
+        assert np.array_equal(s, want.slots), f"traversal {i}: scored order differs"
+        assert np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt)
+        assert st.n_nbr[i] == want.n_nbr
+        assert st.status[i] in (1, 2)
+    t.close()
+
+
+@pytest.mark.parametrize("ndim,n,M,cap0,n_to_score", [
+    (1024, 4096, 8, 16, 1000),
+    (1024, 30000, 8, 16, 5000),
+    (2048, 9000, 32, 64, 3000),
+    (64, 1000, 4, 8, 300),
+    (1024, 5000, 8, 16, 5000),      # score everything: queue drains
+])
+def test_traversal_synthetic_graph(gpu, oracle, ndim, n, M, cap0, n_to_score):
+    idx = _mk_index(ndim, M, cap0)
+    idx.synth_vectors(n, seed=3, mode=1)
+    idx.synth_graph(seed=4)
+    X = oracle.synth_rows(0, n, n, ndim, 3, 1)
+    g = oracle.synth_graph(n, M, cap0, 4)
+    Q = X[[0, 17, n // 2, n - 1, 5, 6, 7]].copy()
+    _check_traversal(oracle, idx, g, X, Q, n_to_score)
+
+
+@pytest.mark.parametrize("ndim,n,M,ef", [(1024, 3000, 8, 64), (64, 1000, 4, 20)])
+def test_traversal_built_graph(gpu, oracle, ndim, n, M, ef):
+    """Graph built by the oracle's usearch-shaped builder, loaded via load_graph."""
+    X = oracle.synth_rows(0, n, n, ndim, 21, 1 if ndim >= 512 else 0)
+    h = oracle.Hnsw(ndim, M, 2 * M, ef, seed=7)
+    h.add(X, max_batch=1)
+    g = h.graph()
+    idx = _mk_index(ndim, M, 2 * M)
+    idx.load_vectors(X)
+    idx.load_graph(g.levels, g.adj0, g.upper_row, g.adjU, g.max_level, g.entry)
+    rng = np.random.default_rng(1)
+    Q = np.concatenate([X[:4], rng.integers(0, 256, (3, X.shape[1]), dtype=np.uint8)])
+    _check_traversal(oracle, idx, g, X, Q, 700)
+    # adjacency reads through the C ABI
+    for slot in (0, 1, n - 1, g.entry):
+        for lv in range(int(g.levels[slot]) + 1):
+            assert np.array_equal(idx.get_neighbors(slot, lv), g.neighbors(slot, lv))
+    assert np.array_equal(idx.get_top_level_nodes(), g.top_level())
+
+
+def test_traversal_resume_in_rounds(gpu, oracle):
+    """Bounded rounds (max_pops) must give the same result as one run."""
+    from rad_amd.device import DeviceTraversal
+    n, ndim = 20000, 1024
+    idx = _mk_index(ndim, 8, 16)
+    idx.synth_vectors(n, seed=3, mode=1)
+    idx.synth_graph(seed=4)
+    X = oracle.synth_rows(0, n, n, ndim, 3, 1)
+    Q = X[:9].copy()
+    t1 = DeviceTraversal(idx, Q, 4000)
+    assert t1.run() == 0
+    t2 = DeviceTraversal(idx, Q, 4000)
+    rounds = 0
+    while t2.run(max_pops=37) > 0:
+        rounds += 1
+        assert rounds < 10000
+    assert rounds > 3
+    for i in range(Q.shape[0]):
+        for x, y in zip(t1.results(i), t2.results(i)):
+            assert np.array_equal(x, y)
+    # reset re-arms the same state
+    t2.reset(Q[::-1].copy())
+    assert t2.run() == 0
+    for i in range(Q.shape[0]):
+        for x, y in zip(t1.results(i), t2.results(Q.shape[0] - 1 - i)):
+            assert np.array_equal(x, y)

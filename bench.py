@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — RAD HNSW neighbor-expansion throughput on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on; it fits
+one GPU): 100M x 1024-bit fingerprints resident in HBM, layered adjacency (connectivity 8,
+level-0 width 16), `nq` independent best-first RAD traversals (Tanimoto-scored) each run
+to n_to_score = 100k scored nodes.  One "step" = one pass of the hot path over one batch
+of nq synthetic queries: state re-arm (device memsets + query upload) + traversal kernel
+launch(es) to completion.  Corpus and graph are synthetic (closed-form generators on the
+device; no dataset or built index can be downloaded here) and are resident in HBM before
+the timed region starts.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): weak scaling — every rank
+holds its own 100M-row shard of an N x 100M corpus with its shard-local graph and runs the
+same query batch against it; value = expansions of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=100_000_000, help="rows per GPU")
+    ap.add_argument("--ndim", type=int, default=1024)
+    ap.add_argument("--connectivity", type=int, default=8)
+    ap.add_argument("--nq", type=int, default=4096, help="concurrent traversals per GPU per step")
+    ap.add_argument("--n-to-score", type=int, default=100_000)
+    ap.add_argument("--corpus-mode", type=int, default=1, help="0 dense Bernoulli(0.5), 1 clustered sparse")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-traversals", type=int, default=0, help="0 = 8 per host core")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    dist = None
+    if world > 1:
+        # torch is plumbing only: rendezvous, barrier, max-over-ranks
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    from rad_amd import _lib
+    from rad_amd.device import DeviceIndex, DeviceTraversal
+
+    _lib.lib()
+    if _lib.device_count() <= local_rank:
+        raise SystemExit("bench.py needs an MI355X per rank; there is no CPU fallback")
+
+    def barrier_sync():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    n, ndim, M = args.n, args.ndim, args.connectivity
+    n_total = n * world
+    idx = DeviceIndex(ndim, M, 2 * M, 64, device=local_rank)
+    idx.synth_vectors(n, seed=20260101, mode=args.corpus_mode, first_row=rank * n, n_total=n_total)
+    idx.synth_graph(seed=777 + rank)
+    info = idx.info()
+    B = info.row_stride
+
+    # query batches: rows of the logical corpus (identical on every rank), a different batch per step
+    n_batches = args.warmup + args.steps
+    qrng = np.random.default_rng(4242)
+    batches = []
+    for b in range(n_batches):
+        first = int(qrng.integers(0, n - args.nq))
+        batches.append(idx.read_vectors(first, args.nq))
+    trav = DeviceTraversal(idx, batches[0], args.n_to_score)
+
+    def step(b):
+        trav.reset(batches[b])
+        running = trav.run(0)
+        assert running == 0
+        ms, launches = trav.kernel_time()
+        st = trav.stats()
+        return ms, launches, int(st.n_pops.sum()), int(st.n_scored.sum()), int(st.n_nbr.sum())
+
+    for w in range(args.warmup):
+        step(w)
+
+    barrier_sync()
+    t0 = time.perf_counter()
+    k_ms = 0.0
+    k_launches = pops = evals = nbrs = 0
+    for s in range(args.steps):
+        ms, launches, p, e, nb = step(args.warmup + s)
+        k_ms += ms
+        k_launches += launches
+        pops += p
+        evals += e
+        nbrs += nb
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+
+    tot = np.array([elapsed, float(pops), float(evals), k_ms, float(k_launches)], dtype=np.float64)
+    if dist is not None:
+        import torch
+        tt = torch.tensor(tot, device="cuda")
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_max = float(tmax[0].item())
+        pops_all, evals_all = float(tsum[1].item()), float(tsum[2].item())
+    else:
+        elapsed_max, pops_all, evals_all = elapsed, float(pops), float(evals)
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # roofline of the dominant kernel (trav_kernel) on rank 0: algorithmic bytes per launch =
+    # evals x (B + 4) [fingerprint row + its u32 slot in the adjacency row] + pops x 4 [degree word]
+    alg_bytes_per_launch = (evals * (B + 4) + pops * 4) / max(k_launches, 1)
+    avg_launch_ms = k_ms / max(k_launches, 1)
+    achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(prof):
+        try:
+            with open(prof) as f:
+                pj = json.load(f)
+            if pj.get("n") == n and pj.get("nq") == args.nq and pj.get("n_to_score") == args.n_to_score:
+                traffic = pj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "neighbor-expansions/sec (1024-bit Tanimoto) + HBM GB/s vs roofline",
+        "value": pops_all / elapsed_max,
+        "unit": "expansions/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed_max / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64 popcount (integer)",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{n * world // 1_000_000}M x {ndim}-bit fingerprints ({n // 1_000_000}M per GPU resident in HBM), "
+                        f"connectivity={M} (level-0 width {2 * M}), {args.nq} concurrent best-first RAD traversals per GPU "
+                        f"to n_to_score={args.n_to_score}, synthetic corpus+graph",
+            "rows_per_gpu": n, "ndim": ndim, "connectivity": M, "nq_per_gpu": args.nq,
+            "n_to_score": args.n_to_score, "corpus_mode": args.corpus_mode,
+            "parallelism": "1 process per GPU, corpus sharded by contiguous row range" if world > 1 else "single GPU",
+        },
+        "evals_per_s": evals_all / elapsed_max,
+        "evals_per_expansion": evals_all / max(pops_all, 1.0),
+        "roofline": {
+            "bound": "hbm", "kernel": "trav_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_launch_ms,
+            "launches": k_launches,
+        },
+    }
+
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(idx, batches[args.warmup], args)
+
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(idx, queries, args):
+    """The oracle (C restatement of the reference control flow, pthreads over independent
+    traversals) timed on this box's host cores, on a bounded sample of the same workload:
+    same corpus + graph (copied back from HBM), same n_to_score, fewer traversals."""
+    from oracle import rad_oracle as O
+    O.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    info = idx.info()
+    n = info.n
+    X = np.empty((n, idx.row_bytes), np.uint8)
+    chunk = 4_000_000
+    for f in range(0, n, chunk):
+        c = min(chunk, n - f)
+        X[f:f + c] = idx.read_vectors(f, c)
+    levels, adj0, upper_row, adjU = idx.read_graph()
+    g = O.Graph(int(n), int(info.connectivity_base), int(info.connectivity), int(info.max_level),
+                int(info.entry), levels, adj0, upper_row, adjU)
+    nt = args.cpu_traversals or 8 * cores
+    nt = min(nt, queries.shape[0])
+    t0 = time.perf_counter()
+    n_scored, n_pops, n_nbr = O.rad_traverse_many(g, X, queries[:nt], args.n_to_score, cores)
+    dt = time.perf_counter() - t0
+    return {"value": float(n_pops.sum()) / dt, "unit": "expansions/s", "cores": cores, "kind": "port",
+            "evals_per_s": float(n_scored.sum()) / dt,
+            "sample": f"{nt} of the {queries.shape[0]} traversals of one step (same corpus, graph, n_to_score), "
+                      f"{dt:.1f} s wall on {cores} threads; usearch-shaped C restatement (oracle/), not usearch"}
+
+
+if __name__ == "__main__":
+    main()

@@ -24,10 +24,28 @@
 #include <algorithm>
 #include <new>
 
-#define S_CAP 1024u
-#define MAX_RUNS 256u
-#define HT_EMPTY 0xFFFFFFFFu
+#ifndef RH_S_CAP
+#define RH_S_CAP 512
+#endif
+#ifndef RH_MAX_RUNS
+#define RH_MAX_RUNS 512
+#endif
+#define S_CAP ((uint32_t)RH_S_CAP)
+#define MAX_RUNS ((uint32_t)RH_MAX_RUNS)
+#define HT_EMPTY64 0xFFFFFFFFFFFFFFFFull
 #define VAL_V0 (1u << 24)
+#define VAL_PENDING 0xFFFFFFFEu
+
+// One wave per workgroup: LDS traffic of a single wave is executed in issue
+// order, so cross-lane hand-offs through LDS need only a compiler barrier — not
+// the s_waitcnt vmcnt(0) that __syncthreads() adds (it would stall on every
+// outstanding global store).
+#define WSYNC()                                                  \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
 
 struct TravHeader {
     uint64_t n_scored, n_pops, n_nbr, pq_used, n_upper;
@@ -44,7 +62,7 @@ struct TravParams {
     uint64_t n_to_score, max_pops;
     TravHeader *hdr;
     const uint4 *queries;
-    uint2 *ht;
+    unsigned long long *ht;  // {slot | val<<32}
     uint32_t ht_log2;
     unsigned long long *ut;
     uint32_t ut_log2;
@@ -78,8 +96,6 @@ __device__ __forceinline__ void st_relaxed(uint32_t *p, uint32_t v) {
 struct TravLds {
     unsigned long long stg[S_CAP];
     unsigned long long rkey[MAX_RUNS];
-    uint32_t rpos[MAX_RUNS];
-    uint32_t rend[MAX_RUNS];
     uint32_t new_slot[64];
     uint32_t new_and[64];
     uint32_t new_or[64];
@@ -96,7 +112,7 @@ __device__ void lds_bitonic_sort(unsigned long long *s, uint32_t P, uint32_t lan
                 const unsigned long long a = s[i], b = s[ixj];
                 if ((a > b) == up) { s[i] = b; s[ixj] = a; }
             }
-            __syncthreads();
+            WSYNC();
         }
     }
 }
@@ -116,7 +132,7 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
     const uint32_t qpop = H->qpop;
     uint32_t primed = H->primed;
 
-    uint2 *ht = P.ht + ((uint64_t)q << P.ht_log2);
+    unsigned long long *ht = P.ht + ((uint64_t)q << P.ht_log2);
     const uint32_t ht_shift = 32u - P.ht_log2;
     const uint32_t ht_mask = (1u << P.ht_log2) - 1u;
     unsigned long long *ut = P.ut + ((uint64_t)q << P.ut_log2);
@@ -131,13 +147,12 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
 
     // ---- restore LDS state ------------------------------------------------
     for (uint32_t i = lane; i < cnt; i += 64) L.stg[i] = P.stg_save[(uint64_t)q * S_CAP + i];
+    uint2 *runs = P.runs_save + (uint64_t)q * MAX_RUNS;  // {pos, end} of every run, live in HBM
     for (uint32_t r = lane; r < n_runs; r += 64) {
-        const uint2 pe = P.runs_save[(uint64_t)q * MAX_RUNS + r];
-        L.rpos[r] = pe.x;
-        L.rend[r] = pe.y;
+        const uint2 pe = runs[r];
         L.rkey[r] = pe.x < pe.y ? pq[pe.x] : RH_KEY_INF;
     }
-    __syncthreads();
+    WSYNC();
 
     // ---- flush staging into a new sorted run --------------------------------
     auto flush = [&]() {
@@ -145,7 +160,7 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
         uint32_t Pw = 2;
         while (Pw < cnt) Pw <<= 1;
         for (uint32_t i = cnt + lane; i < Pw; i += 64) L.stg[i] = RH_KEY_INF;
-        __syncthreads();
+        WSYNC();
         lds_bitonic_sort(L.stg, Pw, lane);
         // pick a run slot: reuse an exhausted one, else append
         uint32_t r = n_runs;
@@ -161,15 +176,14 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
         }
         for (uint32_t i = lane; i < cnt; i += 64) pq[pq_used + i] = L.stg[i];
         if (lane == 0) {
-            L.rpos[r] = (uint32_t)pq_used;
-            L.rend[r] = (uint32_t)(pq_used + cnt);
+            runs[r] = make_uint2((uint32_t)pq_used, (uint32_t)(pq_used + cnt));
             L.rkey[r] = L.stg[0];
         }
         if (r == n_runs) n_runs++;
         pq_used += cnt;
         cnt = 0;
-        __threadfence_block();
-        __syncthreads();
+        __threadfence_block();  // run keys + {pos,end} are re-read by this wave later
+        WSYNC();
     };
 
     // ---- visited / scored / evaluate / enqueue for up to 64 candidate slots --
@@ -195,25 +209,28 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
             if (n_upper > ut_limit) { status = RADHIP_E_CAPACITY; return; }
         }
         bool isnew = false;
-        uint32_t h = 0;
+        uint32_t h = 0, val = 0;
         if (go) {
+            // one 64-bit CAS both claims an empty bucket and returns the stored
+            // value of a present node: a single L2 round trip per probe
+            const unsigned long long mine = (unsigned long long)slot | ((unsigned long long)VAL_PENDING << 32);
             h = (slot * 2654435769u) >> ht_shift;
             for (;;) {
-                const uint32_t old = atomicCAS(&ht[h].x, HT_EMPTY, slot);
-                if (old == HT_EMPTY) { isnew = true; break; }
-                if (old == slot) break;
+                const unsigned long long old = atomicCAS(&ht[h], HT_EMPTY64, mine);
+                if (old == HT_EMPTY64) { isnew = true; break; }
+                if ((uint32_t)old == slot) { val = (uint32_t)(old >> 32); break; }
                 h = (h + 1u) & ht_mask;
             }
         }
+        uint32_t *const vptr = reinterpret_cast<uint32_t *>(&ht[h]) + 1;
         uint32_t a = 0, o = 0;
         bool push = false;
         if (go && !isnew) {
-            const uint32_t val = ld_relaxed(&ht[h].y);
             a = val & 0xFFFu;
             o = (val >> 12) & 0xFFFu;
             if (level == 0) {
                 if (!(val & VAL_V0) || prime) {
-                    st_relaxed(&ht[h].y, val | VAL_V0);
+                    st_relaxed(vptr, val | VAL_V0);
                     push = true;
                 }
             } else {
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
         const uint32_t rank = (uint32_t)__popcll(nb & lt_mask);
         if (nn) {
             if (isnew) L.new_slot[rank] = slot;
-            __syncthreads();
+            WSYNC();
             constexpr uint32_t RPP = 64 / LPR;  // rows per pass
             for (uint32_t base = 0; base < nn; base += RPP) {
                 const uint32_t ri = base + lane / LPR;
@@ -238,11 +255,11 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
                     L.new_or[ri] = qpop + rp - aa;
                 }
             }
-            __syncthreads();
+            WSYNC();
             if (isnew) {
                 a = L.new_and[rank];
                 o = L.new_or[rank];
-                st_relaxed(&ht[h].y, a | (o << 12) | (level == 0 ? VAL_V0 : 0u));
+                st_relaxed(vptr, a | (o << 12) | (level == 0 ? VAL_V0 : 0u));
                 scored[n_scored + rank] = make_uint2(slot, a | (o << 16));
                 push = true;
             }
@@ -255,7 +272,7 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
             if (push) L.stg[cnt + pr] = rh_make_key(rh_q24(a, o), slot, level);
             cnt += (uint32_t)__popcll(pb);
         }
-        __syncthreads();
+        WSYNC();
     };
 
     // ---- prime ---------------------------------------------------------------
@@ -296,15 +313,16 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
         if (wsrc & 0x80000000u) {
             const uint32_t r = wsrc & 0x7FFFFFFFu;
             if (lane == 0) {
-                const uint32_t pos = L.rpos[r] + 1u;
-                L.rpos[r] = pos;
-                L.rkey[r] = pos < L.rend[r] ? pq[pos] : RH_KEY_INF;
+                uint2 pe = runs[r];
+                pe.x += 1u;
+                runs[r] = pe;
+                L.rkey[r] = pe.x < pe.y ? pq[pe.x] : RH_KEY_INF;
             }
         } else {
             if (lane == 0) L.stg[wsrc] = L.stg[cnt - 1u];
             cnt--;
         }
-        __syncthreads();
+        WSYNC();
         uint32_t node, level;
         rh_decode_key(mk, &node, &level);
         if (P.poplog_nodes && n_pops < P.poplog_cap && lane == 0) {
@@ -341,14 +359,17 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
                     }
                 } else {
                     uint32_t h = (node * 2654435769u) >> ht_shift;
+                    unsigned long long e;
                     for (;;) {  // node is scored, hence present
-                        const uint32_t old = ld_relaxed(&ht[h].x);
-                        if (old == node) break;
-                        if (old == HT_EMPTY) break;  // unreachable by construction
+                        e = __hip_atomic_load(&ht[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((uint32_t)e == node || e == HT_EMPTY64) break;  // EMPTY unreachable by construction
                         h = (h + 1u) & ht_mask;
                     }
-                    const uint32_t val = ld_relaxed(&ht[h].y);
-                    if (!(val & VAL_V0)) { st_relaxed(&ht[h].y, val | VAL_V0); push0 = true; }
+                    const uint32_t val = (uint32_t)(e >> 32);
+                    if ((uint32_t)e == node && !(val & VAL_V0)) {
+                        st_relaxed(reinterpret_cast<uint32_t *>(&ht[h]) + 1, val | VAL_V0);
+                        push0 = true;
+                    }
                 }
                 if (push0) {
                     const uint64_t qbits = mk >> 38;
@@ -360,14 +381,12 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
                 cnt++;
                 if (nl > 0) n_upper++;
             }
-            __syncthreads();
+            WSYNC();
         }
     }
 
     // ---- persist ---------------------------------------------------------------
     for (uint32_t i = lane; i < cnt; i += 64) P.stg_save[(uint64_t)q * S_CAP + i] = L.stg[i];
-    for (uint32_t r = lane; r < n_runs; r += 64)
-        P.runs_save[(uint64_t)q * MAX_RUNS + r] = make_uint2(L.rpos[r], L.rend[r]);
     if (lane == 0) {
         H->n_scored = n_scored; H->n_pops = n_pops; H->n_nbr = n_nbr; H->pq_used = pq_used;
         H->n_upper = n_upper; H->stg_cnt = cnt; H->n_runs = n_runs; H->primed = primed;
@@ -469,7 +488,7 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     P.n_to_score = n_to_score; P.max_pops = 0;
     P.ht_log2 = ht_log2; P.ut_log2 = ut_log2; P.scored_cap = scored_cap; P.pq_cap = pq_cap;
     t->hdr_bytes = (size_t)nq * sizeof(TravHeader);
-    t->ht_bytes = ((size_t)nq << ht_log2) * sizeof(uint2);
+    t->ht_bytes = ((size_t)nq << ht_log2) * 8;
     t->ut_bytes = ((size_t)nq << ut_log2) * 8;
     t->scored_bytes = (size_t)nq * scored_cap * sizeof(uint2);
     t->pq_bytes = (size_t)nq * pq_cap * 8;

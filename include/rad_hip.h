@@ -136,6 +136,27 @@ int radhip_tanimoto_gather(radhip_index_t *idx, const uint8_t *queries, uint32_t
 /* float edge value: 1.0f - (float)and/(float)or, 0.0f when or == 0 */
 float radhip_distance_f32(uint32_t and_cnt, uint32_t or_cnt);
 
+/* ---- A2: usearch-shaped HNSW insert + search on the device -------------- */
+/* replaces usearch Index.add(keys, fps) — README.md:58,
+ * examples/DUDEZ_example.ipynb:192: appends `count` rows (slots n .. n+count-1) to the corpus
+ * and links them into the layered graph: integer geometric level draw from (seed, slot),
+ * greedy descent, best-first layer search with expansion_add, heuristic neighbour selection,
+ * reverse edges with re-selection.  Inserts run in deterministic batches of size
+ * clamp(start/16, 1, max_batch) that search the pre-batch graph; max_batch = 1 is the
+ * classical sequential insert.  (usearch's own source is not in the reference tree: the
+ * algorithm is restated in oracle/rad_oracle.c orc_hnsw_add, parity unpinned vs usearch.) */
+int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64_t count, uint64_t seed,
+                     uint32_t max_batch);
+/* replaces usearch Index.search(vectors, count) (never called by RAD itself; the same inner
+ * loop as add): k nearest of each query by best-first search with expansion ef >= k.
+ * out_* are [nq*k]; out_counts[nq]; out_evals/out_pops (optional) count Tanimoto
+ * evaluations / node expansions per query. */
+int radhip_search(radhip_index_t *idx, const uint8_t *queries, uint32_t nq, uint32_t k, uint32_t ef,
+                  uint32_t *out_slots, uint32_t *out_and, uint32_t *out_or, uint32_t *out_counts,
+                  uint64_t *out_evals, uint64_t *out_pops);
+/* level a node inserted at `slot` gets (host arithmetic, integer only) */
+int radhip_level_of(uint64_t seed, uint64_t slot, uint32_t connectivity);
+
 /* ---- A5-A10: RAD best-first traversal, Tanimoto-scored, on the device --- */
 /* One independent traversal per query: prime (rad/traverser.py:128-176) from
  * the top-level nodes at level max(0, max_level-1), then pop-min / expand /

@@ -62,6 +62,9 @@ SIGNATURES = {
     "radhip_tanimoto_scan": (C.c_int, [_P, _P, _U32, _U64, _U64, _P, _P]),
     "radhip_tanimoto_gather": (C.c_int, [_P, _P, _U32, _P, _P, _P, _P]),
     "radhip_distance_f32": (C.c_float, [_U32, _U32]),
+    "radhip_index_add": (C.c_int, [_P, _P, _U64, _U64, _U32]),
+    "radhip_search": (C.c_int, [_P, _P, _U32, _U32, _U32, _P, _P, _P, _P, _P, _P]),
+    "radhip_level_of": (C.c_int, [_U64, _U64, _U32]),
     "radhip_traversal_create": (C.c_int, [_P, _P, _U32, _U64, _U32, C.POINTER(_P)]),
     "radhip_traversal_destroy": (C.c_int, [_P]),
     "radhip_traversal_reset": (C.c_int, [_P, _P]),

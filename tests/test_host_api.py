@@ -1,0 +1,315 @@
+"""Host-side API parity against golden vectors captured from the reference's own modules
+(tests/golden/make_golden.py).  No GPU: state backends, coordinator, worker, traverser,
+HNSW service, and the C-ABI library's symbol table."""
+import os
+import re
+import sqlite3
+
+import numpy as np
+import pytest
+
+from golden_util import golden, load_graph_npz
+
+NO_SLOT = 0xFFFFFFFF
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------- C ABI surface
+def test_library_exports_every_declared_symbol():
+    from rad_amd import _lib
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "rad_hip.h")).read()
+    declared = set(re.findall(r"\b(radhip_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(L, name), f"librad_hip.so lacks {name}"
+        assert name in _lib.SIGNATURES, f"rad_amd/_lib.py does not bind {name}"
+    assert L.radhip_backend_name() == b"hip:gfx950"
+
+
+def test_device_entry_points_fail_loudly_without_gpu():
+    """No CPU fallback: on a box without a GPU every compute call raises."""
+    from rad_amd import _lib
+    from rad_amd.device import DeviceIndex
+    if _lib.device_count() > 0:
+        pytest.skip("GPU present")
+    idx = DeviceIndex(64, 4)
+    idx.load_vectors(np.zeros((10, 8), np.uint8))
+    with pytest.raises(_lib.RadHipError) as e:
+        idx.scan(np.zeros((1, 8), np.uint8))
+    assert e.value.code == _lib.E_NO_DEVICE
+
+
+# ----------------------------------------------------------------- state backends
+def test_priority_queue_order_matches_redis_zset():
+    from rad_amd.priority_queue import InProcessPQ
+    g = golden()["g2"]
+    pq = InProcessPQ()
+    for nid, lv, sc in g["inserts"]:
+        pq.insert(nid, lv, sc)
+    out = []
+    while True:
+        it = pq.pop()
+        if it is None:
+            break
+        out.append([it[0], it[1], it[2]])
+    assert out == g["pops"]
+    assert pq.pop() is None and len(pq) == 0
+
+
+def test_visited_semantics():
+    from rad_amd.visited import InProcessVisited
+    g = golden()["g3"]
+    vs = InProcessVisited()
+    assert [vs.checkAndInsert(a, b) for a, b in g["calls"]] == g["returns"]
+
+
+def test_scored_set_semantics(tmp_path):
+    from rad_amd.scored import InProcessScoredSet
+    g = golden()["scored"]
+    ss = InProcessScoredSet()
+    for a, b, c in g["inserts"]:
+        ss.insert(a, b, c)
+    assert len(ss) == g["length"]
+    assert [list(x) for x in ss.get_molecules()] == g["molecules"]
+    assert [list(x) for x in ss.get_molecules(2)] == g["first2"]
+    assert [list(x) for x in ss.get_best_molecules()] == g["best"]
+    assert [list(x) for x in ss.get_best_molecules(2)] == g["best2"]
+    assert ss.getScore(7) == g["get7"] and ss.getScore(12345) is g["get_missing"]
+    assert [list(x) for x in ss] == g["iter"]
+    p = tmp_path / "s.txt"
+    ss.save(str(p))
+    assert p.read_text().splitlines()[0] == f"{g['iter'][0][0]} {g['iter'][0][1]}"
+
+
+def test_work_item_dict_shape():
+    from rad_amd.coordination_service import WorkItem
+    g = golden()["g6"]
+    d = WorkItem(5, 2, -1.5, request_id="rid", neighbors=[1, "C"]).to_dict()
+    assert sorted(d.keys()) == g["keys"]
+    assert (d["node_id"], d["level"], d["score"], d["neighbors"]) == (g["node_id"], g["level"], g["score"], g["neighbors"])
+    assert sorted(WorkItem.from_dict(d).to_dict().keys()) == g["roundtrip"]
+
+
+# ----------------------------------------------------------------- traverser vs reference flow
+def _toy_service(z):
+    from rad_amd.hnsw_service import HNSWService
+
+    class Toy(HNSWService):
+        def get_neighbors(self, node_id, level):
+            if level > z["levels"][node_id]:
+                raise KeyError((node_id, level))
+            row = z["adj0"][node_id] if level == 0 else z["adjU"][z["upper_row"][node_id] + level - 1]
+            out = []
+            for nb in row:
+                if nb != NO_SLOT:
+                    out.extend([int(nb), f"S{int(nb)}"])
+            return out
+
+        def get_top_level_nodes(self):
+            out = []
+            for i in np.nonzero(z["levels"] == int(z["max_level"]))[0]:
+                out.extend([int(i), f"S{int(i)}"])
+            return out
+
+        def is_healthy(self):
+            return True
+
+        def shutdown(self):
+            pass
+
+        def get_service_info(self):
+            return {"service_type": "Toy"}
+
+        def get_hnsw_info(self):
+            return {"max_level": int(z["max_level"])}
+    return Toy()
+
+
+def _hash_score(smiles):
+    h = 1469598103934665603
+    for ch in smiles.encode():
+        h = ((h ^ ch) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return -20.0 + (h % 100000) / 5000.0
+
+
+class _PopLogPQ:
+    """Wraps a PriorityQueue to record the pop sequence."""
+
+    def __init__(self, inner):
+        self.inner, self.log = inner, []
+
+    def pop(self):
+        it = self.inner.pop()
+        if it is not None:
+            self.log.append([it[0], it[1], it[2]])
+        return it
+
+    def insert(self, *a, **k):
+        return self.inner.insert(*a, **k)
+
+    def __len__(self):
+        return len(self.inner)
+
+
+def test_traverser_reproduces_reference_traversal_hash_scores():
+    from rad_amd.priority_queue import InProcessPQ
+    from rad_amd.traverser import RADTraverser
+    g = golden()
+    z = load_graph_npz("g1_graph.npz")
+    pq = _PopLogPQ(InProcessPQ())
+    t = RADTraverser(hnsw_service=_toy_service(z), scoring_fn=_hash_score, namespace="g1", priority_queue=pq)
+    t.prime()
+    t.traverse(n_workers=1, n_to_score=g["g1"]["n_to_score"])
+    assert pq.log == g["g1"]["pops"]
+    assert [list(m) for m in t.get_molecules()] == g["g1"]["molecules"]
+    assert [list(m) for m in t.get_best_molecules(10)] == g["g1"]["best10"]
+    assert len(t.scored_set) >= g["g1"]["n_to_score"]
+    # drain the whole graph
+    pq2 = _PopLogPQ(InProcessPQ())
+    t2 = RADTraverser(hnsw_service=_toy_service(z), scoring_fn=_hash_score, priority_queue=pq2)
+    t2.prime()
+    t2.traverse(n_workers=1, n_to_score=10 ** 9)
+    ga = g["g1_all"]
+    assert len(pq2.log) == ga["n_pops"] and len(t2.scored_set) == ga["n_scored"]
+    assert pq2.log[:50] == ga["pops_head"] and pq2.log[-50:] == ga["pops_tail"]
+    assert [list(m) for m in t2.get_molecules()[-50:]] == ga["molecules_tail"]
+    stats = t2.get_traversal_stats()
+    assert stats["coordination"]["scored_molecules"] == ga["n_scored"]
+    assert stats["coordination"]["pending_work"] == 0
+
+
+@pytest.mark.parametrize("tag", ["t64", "t1024"])
+def test_traverser_reproduces_reference_traversal_tanimoto_scores(tag):
+    from rad_amd.priority_queue import InProcessPQ
+    from rad_amd.traverser import RADTraverser
+    z = load_graph_npz(f"g1{tag}_graph.npz")
+    bits = np.unpackbits(z["fps"], axis=1).astype(np.int64)
+    for c in golden()[f"g1{tag}"]:
+        qb = np.unpackbits(z["queries"][c["query"]]).astype(np.int64)
+        a = bits @ qb
+        o = bits.sum(1) + qb.sum() - a
+
+        def score(smiles, a=a, o=o):
+            i = int(smiles[1:])
+            return 0.0 if o[i] == 0 else float(np.float32(1.0) - np.float32(a[i]) / np.float32(o[i]))
+        pq = _PopLogPQ(InProcessPQ())
+        t = RADTraverser(hnsw_service=_toy_service(z), scoring_fn=score, priority_queue=pq)
+        t.prime()
+        t.traverse(n_workers=1, n_to_score=c["n_to_score"])
+        assert [p[0] for p in pq.log] == c["pop_nodes"]
+        assert [p[1] for p in pq.log] == c["pop_levels"]
+        mols = t.get_molecules()
+        assert [m[0] for m in mols] == c["slots"] and [m[1] for m in mols] == c["scores"]
+
+
+def test_multi_worker_traversal_has_no_duplicates_and_terminates():
+    from rad_amd.traverser import RADTraverser
+    z = load_graph_npz("g1_graph.npz")
+    t = RADTraverser(hnsw_service=_toy_service(z), scoring_fn=_hash_score)
+    t.prime()
+    t.traverse(n_workers=4, n_to_score=120)
+    mols = t.get_molecules()
+    assert len(mols) >= 120
+    assert len({m[0] for m in mols}) == len(mols)
+    assert all(isinstance(m[0], int) and isinstance(m[1], float) for m in mols)
+    with pytest.raises(ValueError):
+        RADTraverser(hnsw_service=_toy_service(z), scoring_fn=_hash_score).traverse(n_workers=1)
+    t3 = RADTraverser(hnsw_service=_toy_service(z), scoring_fn=lambda s: (__import__("time").sleep(0.01), 1.0)[1])
+    t3.prime()
+    import time
+    t0 = time.time()
+    t3.traverse(n_workers=2, timeout=0.3)
+    assert time.time() - t0 < 3.0
+
+
+# ----------------------------------------------------------------- HNSW service + Index host logic
+class MockHNSW:  # reference: tests/test_redis_auth.py:24-43
+    max_level, connectivity, dtype, ndim, capacity, memory_usage, multi = 3, 16, "float32", 256, 1000, 1024, False
+
+    def __len__(self):
+        return 100
+
+    def get_neighbors(self, node_id, level):
+        return [1, 101, 2, 102, 3, 103]
+
+    def get_top_level_nodes(self):
+        return [0, 100, 1, 101, 2, 102]
+
+
+def test_local_hnsw_service_matches_reference_round_trip(tmp_path):
+    from rad_amd.hnsw_service import LocalHNSWService, create_local_hnsw_service, service_registry
+    g = golden()["g5"]
+    svc = LocalHNSWService(MockHNSW())
+    assert svc.get_neighbors(0, 0) == g["neighbors_no_db"]
+    assert svc.get_top_level_nodes() == g["top_no_db"]
+    assert svc.get_hnsw_info() == g["hnsw_info"]
+    assert sorted(svc.get_service_info().keys()) == g["service_info_keys"]
+    assert svc.is_healthy() == g["healthy"]
+    svc.shutdown()
+    assert svc.is_healthy() == g["healthy_after_shutdown"]
+    with pytest.raises(RuntimeError):
+        svc.get_neighbors(0, 0)
+    db = str(tmp_path / "m.db")
+    con = sqlite3.connect(db)
+    con.execute("CREATE TABLE nodes (node_key INTEGER PRIMARY KEY, smi TEXT NOT NULL)")
+    con.executemany("INSERT INTO nodes VALUES (?, ?)", [(100, "C"), (101, "CC"), (103, "CCCC")])
+    con.commit()
+    con.close()
+    svc = create_local_hnsw_service(MockHNSW(), database_path=db)
+    assert svc.get_neighbors(0, 0) == g["neighbors_db"]
+    assert svc.get_top_level_nodes() == g["top_db"]
+    assert svc.get_neighbors_many([(0, 0), (5, 1)]) == [g["neighbors_db"], g["neighbors_db"]]
+    assert service_registry.get_service() is svc and service_registry.get_service("local") is svc
+    assert svc.get_service_info()["request_count"] == 3
+
+    class Broken(MockHNSW):
+        def get_neighbors(self, node_id, level):
+            raise KeyError("no such node")
+    with pytest.raises(RuntimeError, match="HNSW request failed"):
+        LocalHNSWService(Broken()).get_neighbors(1, 1)
+    service_registry.shutdown_all()
+    with pytest.raises(ValueError):
+        service_registry.get_service()
+
+
+def test_index_serves_adjacency_without_gpu(tmp_path):
+    """An Index holding only a graph (exclude_vectors) answers RAD's adjacency calls from the
+    library's host mirror — as the reference's server does with view=True, exclude_vectors=True."""
+    from rad_amd.hnsw_service import LocalHNSWService
+    from rad_amd.index import Index
+    from rad_amd._lib import RadHipError
+    z = load_graph_npz("g1t64_graph.npz")
+    n = z["levels"].shape[0]
+    keys = np.arange(n, dtype=np.uint64) * 7 + 1000
+    idx = Index(ndim=64, dtype="b1", metric="tanimoto", connectivity=4, expansion_add=20)
+    idx.load_graph(keys, None, z["levels"], z["adj0"], z["upper_row"], z["adjU"], int(z["max_level"]), int(z["entry"]))
+    assert len(idx) == n and idx.max_level == int(z["max_level"]) and idx.connectivity == 4
+    assert idx.ndim == 64 and idx.multi is False and str(idx.dtype) == "b1" and idx.capacity == n
+    row = [int(x) for x in z["adj0"][5] if x != NO_SLOT]
+    flat = [int(x) for x in idx.get_neighbors(5, 0)]
+    assert flat[0::2] == row and flat[1::2] == [int(keys[r]) for r in row]
+    tops = np.nonzero(z["levels"] == int(z["max_level"]))[0]
+    assert [int(x) for x in idx.get_top_level_nodes()][0::2] == tops.tolist()
+    assert idx.get_node_ids_from_keys([1007, 1000]).tolist() == [1, 0]
+    with pytest.raises(RadHipError):
+        idx.get_neighbors(5, int(z["levels"][5]) + 1)     # node absent on that level
+    with pytest.raises(RadHipError):
+        idx.get_neighbors(n + 5, 0)
+    svc = LocalHNSWService(idx)
+    out = svc.get_neighbors(5, 0)
+    assert out[0::2] == row and all(s == "" for s in out[1::2])
+    assert svc.get_hnsw_info()["max_level"] == int(z["max_level"]) and svc.get_hnsw_info()["size"] == n
+    ls = idx.levels_stats
+    assert ls[0].nodes == n and ls[0].edges == int((z["adj0"] != NO_SLOT).sum())
+    # duplicate / self / out-of-range targets are rejected at load time
+    bad = z["adj0"].copy()
+    bad[3, 1] = bad[3, 0]
+    with pytest.raises(RadHipError):
+        Index(ndim=64, connectivity=4).load_graph(None, None, z["levels"], bad, z["upper_row"], z["adjU"],
+                                                   int(z["max_level"]), int(z["entry"]))
+    # save / load round trip of a vector-less index
+    p = str(tmp_path / "idx.npz")
+    idx.save(p)
+    idx2 = Index(path=p, view=True, exclude_vectors=True)
+    assert [int(x) for x in idx2.get_neighbors(5, 0)] == flat and len(idx2) == n

@@ -200,6 +200,25 @@ int radhip_traversal_kernel_time(const radhip_traversal_t *t, double *out_ms,
                                  uint64_t *out_launches);
 uint64_t radhip_traversal_state_bytes(const radhip_traversal_t *t);
 
+/* per-traversal stop targets (each clamped to n_to_score): a traversal parks (status 3) once
+ * n_scored >= its target and resumes when the target is raised — the hook the sharded
+ * multi-GPU traversal uses to split a global n_to_score over shards round by round. */
+int radhip_traversal_set_targets(radhip_traversal_t *t, const uint64_t *targets /* [nq] */);
+/* frontier candidate scores: the best key left in each traversal's queue when the kernel
+ * last returned (UINT64_MAX = queue empty; bits 61..38 hold the 24-bit distance q), and the
+ * scored counts — what the ranks all-gather between rounds. */
+int radhip_traversal_frontier(const radhip_traversal_t *t, uint64_t *out_keys, uint64_t *out_scored);
+
+/* ---- multi-GPU exchange: RCCL over xGMI, one process per GPU -------------------- */
+typedef struct radhip_comm radhip_comm_t;
+int radhip_comm_unique_id(uint8_t *out128);          /* rank 0 creates, host hands to others */
+int radhip_comm_create(int rank, int world, const uint8_t *id128, int device, radhip_comm_t **out);
+int radhip_comm_destroy(radhip_comm_t *c);
+/* ncclAllGather of `count` u64 words per rank (host buffers are staged through HBM) */
+int radhip_comm_allgather_u64(radhip_comm_t *c, const uint64_t *send, uint64_t count, uint64_t *recv);
+int radhip_comm_rank(const radhip_comm_t *c);
+int radhip_comm_world(const radhip_comm_t *c);
+
 /* host restatement of the device queue key, exported so CPU tests can check
  * its order against the Redis ZSET order of rad/priority_queue.py:22-42
  * (ascending score, ties by bytes of "{node_id}:{level}") */

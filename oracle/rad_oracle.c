@@ -320,6 +320,12 @@ done:
         stats->n_pops = n_pops;
         stats->n_evals = n_scored;
         stats->n_nbr = n_nbr;
+        stats->f_valid = pq.n > 0;
+        stats->f_and = pq.n ? pq.v[0].and_cnt : 0;
+        stats->f_or = pq.n ? pq.v[0].or_cnt : 0;
+        stats->f_slot = pq.n ? pq.v[0].slot : 0;
+        stats->f_level = pq.n ? pq.v[0].level : 0;
+        stats->f_pad = 0;
     }
     free(pq.v);
     hset_free(&visited);

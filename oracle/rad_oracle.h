@@ -82,6 +82,8 @@ typedef struct {
     uint64_t n_pops;     /* node expansions performed                         */
     uint64_t n_evals;    /* Tanimoto evaluations (== n_scored)                */
     uint64_t n_nbr;      /* adjacency entries examined                        */
+    /* best item left in the queue when the traversal stopped (frontier candidate) */
+    uint32_t f_valid, f_and, f_or, f_slot, f_level, f_pad;
 } orc_trav_stats_t;
 
 /* Runs prime + best-first traversal until n_scored >= n_to_score, the queue

@@ -38,7 +38,9 @@ class _Graph(C.Structure):
 
 class _Stats(C.Structure):
     _fields_ = [("n_scored", C.c_uint64), ("n_pops", C.c_uint64),
-                ("n_evals", C.c_uint64), ("n_nbr", C.c_uint64)]
+                ("n_evals", C.c_uint64), ("n_nbr", C.c_uint64),
+                ("f_valid", C.c_uint32), ("f_and", C.c_uint32), ("f_or", C.c_uint32),
+                ("f_slot", C.c_uint32), ("f_level", C.c_uint32), ("f_pad", C.c_uint32)]
 
 
 _lib = None
@@ -157,6 +159,7 @@ class TraverseResult:
     pop_levels: np.ndarray
     n_pops: int
     n_nbr: int
+    frontier: tuple = None   # (and, or, slot, level) of the best item left in the queue, or None
 
 
 def rad_traverse(graph: Graph, corpus: np.ndarray, query: np.ndarray, n_to_score: int,
@@ -182,7 +185,8 @@ def rad_traverse(graph: Graph, corpus: np.ndarray, query: np.ndarray, n_to_score
     return TraverseResult(s[:k].copy(), a[:k].copy(), o[:k].copy(),
                           pn[:np_].copy() if log_pops else np.empty(0, np.uint32),
                           pl[:np_].copy() if log_pops else np.empty(0, np.uint8),
-                          int(st.n_pops), int(st.n_nbr))
+                          int(st.n_pops), int(st.n_nbr),
+                          (int(st.f_and), int(st.f_or), int(st.f_slot), int(st.f_level)) if st.f_valid else None)
 
 
 def rad_traverse_many(graph: Graph, corpus: np.ndarray, queries: np.ndarray, n_to_score: int,

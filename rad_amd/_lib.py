@@ -74,6 +74,14 @@ SIGNATURES = {
     "radhip_traversal_pop_log": (C.c_int, [_P, _U32, _P, _P, _U64, C.POINTER(_U64)]),
     "radhip_traversal_kernel_time": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_U64)]),
     "radhip_traversal_state_bytes": (_U64, [_P]),
+    "radhip_traversal_set_targets": (C.c_int, [_P, _P]),
+    "radhip_traversal_frontier": (C.c_int, [_P, _P, _P]),
+    "radhip_comm_unique_id": (C.c_int, [_P]),
+    "radhip_comm_create": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, C.POINTER(_P)]),
+    "radhip_comm_destroy": (C.c_int, [_P]),
+    "radhip_comm_allgather_u64": (C.c_int, [_P, _P, _U64, _P]),
+    "radhip_comm_rank": (C.c_int, [_P]),
+    "radhip_comm_world": (C.c_int, [_P]),
     "radhip_rad_key": (_U64, [_U32, _U32, _U32, _U32]),
     "radhip_rad_key_decode": (None, [_U64, C.POINTER(_U32), C.POINTER(_U32)]),
 }

@@ -49,6 +49,8 @@
 
 struct TravHeader {
     uint64_t n_scored, n_pops, n_nbr, pq_used, n_upper;
+    uint64_t target;        // stop once n_scored >= target (checked before every pop)
+    uint64_t frontier_key;  // best queue key when the kernel last returned (RH_KEY_INF = empty)
     uint32_t stg_cnt, n_runs, qpop, primed;
     int32_t status;
     uint32_t pad;
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
     const uint32_t q = blockIdx.x;
     TravHeader *H = P.hdr + q;
     int32_t status = H->status;
+    if (status == 3 && H->n_scored < H->target) status = 0;  // target was raised: resume
     if (status != 0) return;
 
     uint64_t n_scored = H->n_scored, n_pops = H->n_pops, n_nbr = H->n_nbr, pq_used = H->pq_used,
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
     uint32_t cnt = H->stg_cnt, n_runs = H->n_runs;
     const uint32_t qpop = H->qpop;
     uint32_t primed = H->primed;
+    const uint64_t target = H->target;
 
     unsigned long long *ht = P.ht + ((uint64_t)q << P.ht_log2);
     const uint32_t ht_shift = 32u - P.ht_log2;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
     // ---- best-first loop -------------------------------------------------------
     uint64_t pops_here = 0;
     while (status == 0) {
-        if (n_scored >= P.n_to_score) { status = 1; break; }
+        if (n_scored >= target) { status = target >= P.n_to_score ? 1 : 3; break; }
         if (P.max_pops && pops_here >= P.max_pops) break;
         if (cnt + 66u > S_CAP) { flush(); if (status) break; }
         // pop-min over staging and run heads
@@ -385,12 +389,18 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
         }
     }
 
+    // ---- frontier score: best key left in the queue -------------------------------
+    unsigned long long fbest = RH_KEY_INF;
+    for (uint32_t i = lane; i < cnt; i += 64) fbest = L.stg[i] < fbest ? L.stg[i] : fbest;
+    for (uint32_t r = lane; r < n_runs; r += 64) fbest = L.rkey[r] < fbest ? L.rkey[r] : fbest;
+    fbest = wave_min_u64(fbest);
     // ---- persist ---------------------------------------------------------------
     for (uint32_t i = lane; i < cnt; i += 64) P.stg_save[(uint64_t)q * S_CAP + i] = L.stg[i];
     if (lane == 0) {
         H->n_scored = n_scored; H->n_pops = n_pops; H->n_nbr = n_nbr; H->pq_used = pq_used;
         H->n_upper = n_upper; H->stg_cnt = cnt; H->n_runs = n_runs; H->primed = primed;
         H->status = status;
+        H->frontier_key = fbest;
     }
 }
 
@@ -426,6 +436,8 @@ static int trav_upload_queries(radhip_traversal *t, const uint8_t *queries) {
         uint32_t p = 0;
         for (uint32_t b = 0; b < idx->row_bytes; ++b) p += (uint32_t)__builtin_popcount(queries[(size_t)i * idx->row_bytes + b]);
         hdr[i].qpop = p;
+        hdr[i].target = t->n_to_score;
+        hdr[i].frontier_key = RH_KEY_INF;
     }
     RH_HIP(hipMemcpyAsync(t->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, idx->stream));
     RH_HIP(hipMemcpyAsync(t->P.hdr, hdr.data(), t->hdr_bytes, hipMemcpyHostToDevice, idx->stream));
@@ -563,7 +575,7 @@ extern "C" int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, ui
     uint32_t running = 0;
     int bad = 0;
     for (uint32_t i = 0; i < t->nq; ++i) {
-        if (hdr[i].status == 0) running++;
+        if (hdr[i].status == 0) running++;  // status 3 (intermediate target reached) is parked, not running
         if (hdr[i].status < 0 && !bad) bad = hdr[i].status;
     }
     if (out_running) *out_running = running;
@@ -630,3 +642,32 @@ extern "C" int radhip_traversal_kernel_time(const radhip_traversal_t *t, double 
 }
 
 extern "C" uint64_t radhip_traversal_state_bytes(const radhip_traversal_t *t) { return t ? t->state_bytes : 0; }
+
+extern "C" int radhip_traversal_set_targets(radhip_traversal_t *t, const uint64_t *targets) {
+    if (!t || !targets) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(t->idx->mu);
+    RH_HIP(hipSetDevice(t->idx->device));
+    std::vector<TravHeader> hdr(t->nq);
+    RH_HIP(hipMemcpy(hdr.data(), t->P.hdr, t->hdr_bytes, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < t->nq; ++i) {
+        uint64_t tg = targets[i] < t->n_to_score ? targets[i] : t->n_to_score;
+        hdr[i].target = tg;
+        if (hdr[i].status == 3 && hdr[i].n_scored < tg) hdr[i].status = 0;
+        if (hdr[i].status == 0 && hdr[i].primed && hdr[i].n_scored >= tg) hdr[i].status = tg >= t->n_to_score ? 1 : 3;
+    }
+    RH_HIP(hipMemcpy(t->P.hdr, hdr.data(), t->hdr_bytes, hipMemcpyHostToDevice));
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_traversal_frontier(const radhip_traversal_t *t, uint64_t *out_keys, uint64_t *out_scored) {
+    if (!t) RH_FAIL(RADHIP_E_INVALID, "null traversal");
+    std::lock_guard<std::mutex> lk(t->idx->mu);
+    RH_HIP(hipSetDevice(t->idx->device));
+    std::vector<TravHeader> hdr(t->nq);
+    RH_HIP(hipMemcpy(hdr.data(), t->P.hdr, t->hdr_bytes, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < t->nq; ++i) {
+        if (out_keys) out_keys[i] = hdr[i].frontier_key;
+        if (out_scored) out_scored[i] = hdr[i].n_scored;
+    }
+    return RADHIP_OK;
+}

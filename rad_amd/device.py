@@ -203,6 +203,21 @@ class DeviceTraversal:
         check(self._L.radhip_traversal_pop_log(self._h, q, ptr(nodes), ptr(levels), k, C.byref(n)))
         return nodes, levels
 
+    def set_targets(self, targets) -> None:
+        """Per-traversal stop targets (clamped to n_to_score); raising one resumes a parked traversal."""
+        t = np.ascontiguousarray(targets, np.uint64)
+        if t.shape[0] != self.nq:
+            raise ValueError(f"need {self.nq} targets")
+        check(self._L.radhip_traversal_set_targets(self._h, ptr(t)))
+
+    def frontier(self):
+        """(best queue key, scored count) per traversal after the last run(); key == 2**64-1
+        means the queue is empty; key >> 38 is the 24-bit distance of the best candidate."""
+        k = np.empty(self.nq, np.uint64)
+        n = np.empty(self.nq, np.uint64)
+        check(self._L.radhip_traversal_frontier(self._h, ptr(k), ptr(n)))
+        return k, n
+
     def kernel_time(self):
         ms = C.c_double(0)
         n = C.c_uint64(0)
@@ -213,4 +228,40 @@ class DeviceTraversal:
         return int(self._L.radhip_traversal_state_bytes(self._h))
 
 
-__all__ = ["DeviceIndex", "DeviceTraversal", "TraversalStats", "distance_f32", "NO_SLOT", "RadHipError"]
+class RcclComm:
+    """RCCL communicator of the C ABI (one process per GPU).  `unique_id()` is called on rank 0;
+    the 128 bytes reach the other ranks through whatever channel the host program has."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        check(_lib.lib().radhip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, rank: int, world: int, unique_id: bytes, device: int):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        idb = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(self._L.radhip_comm_create(rank, world, idb, device, C.byref(self._h)))
+
+    def allgather_u64(self, local: np.ndarray) -> np.ndarray:
+        """[count] u64 per rank -> [world, count]"""
+        a = np.ascontiguousarray(local, np.uint64).reshape(-1)
+        out = np.empty((self.world, a.shape[0]), np.uint64)
+        check(self._L.radhip_comm_allgather_u64(self._h, ptr(a), a.shape[0], ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.radhip_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+__all__ = ["RcclComm", "DeviceIndex", "DeviceTraversal", "TraversalStats", "distance_f32", "NO_SLOT", "RadHipError"]

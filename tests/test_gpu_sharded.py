@@ -1,0 +1,113 @@
+"""GPU side of the sharded traversal: per-traversal targets / park / resume and frontier keys
+of trav_kernel against the oracle, two shards driven through the federated rounds on one GPU
+(threads + a barrier standing in for the ranks), and the RCCL communicator with world = 1."""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _device_shard(O, X, g, M, cap0):
+    from rad_amd.device import DeviceIndex
+    idx = DeviceIndex(X.shape[1] * 8, M, cap0, 64)
+    idx.load_vectors(X)
+    idx.load_graph(g.levels, g.adj0, g.upper_row, g.adjU, g.max_level, g.entry)
+    return idx
+
+
+def test_targets_park_resume_and_frontier(gpu, oracle):
+    from rad_amd import _lib
+    from rad_amd.device import DeviceTraversal
+    from sharded_util import make_shards
+    (X, g), = make_shards(oracle, 1, 8000, 1024, 8, 16, 9)
+    idx = _device_shard(oracle, X, g, 8, 16)
+    Q = X[[1, 50, 4000]].copy()
+    t = DeviceTraversal(idx, Q, 2000)
+    key = _lib.lib().radhip_rad_key
+    for tg in ([100, 300, 50], [100, 700, 900], [2000, 2000, 2000]):
+        t.set_targets(np.array(tg, np.uint64))
+        t.run()
+        keys, scored = t.frontier()
+        st = t.stats()
+        for i in range(3):
+            want = oracle.rad_traverse(g, X, Q[i], tg[i], log_pops=False)
+            s, a, o = t.results(i)
+            assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt)
+            assert int(scored[i]) == want.slots.shape[0] and st.n_pops[i] == want.n_pops
+            assert int(keys[i]) == (0xFFFFFFFFFFFFFFFF if want.frontier is None else key(*want.frontier))
+    assert set(t.stats().status.tolist()) <= {1, 2}
+
+
+def test_two_shards_federated_rounds_on_one_gpu(gpu, oracle):
+    from rad_amd.device import DeviceTraversal
+    from rad_amd.sharded import ShardedTraversal, allocate_targets
+    from sharded_util import OracleLocalTraversal, make_shards
+    world, n_per, nts = 2, 6000, 900
+    shards = make_shards(oracle, world, n_per, 1024, 8, 16, 5)
+    Q = oracle.synth_rows(0, 5, world * n_per, 1024, 5, 1)
+    barrier = threading.Barrier(world)
+    slots_box = [None] * world
+    out = [None] * world
+    errs = []
+
+    def allgather_for(rank):
+        def allgather(a):
+            slots_box[rank] = np.asarray(a, np.uint64).copy()
+            barrier.wait(60)
+            res = np.stack(slots_box)
+            barrier.wait(60)
+            return res
+        return allgather
+
+    def run(rank):
+        try:
+            X, g = shards[rank]
+            idx = _device_shard(oracle, X, g, 8, 16)
+            local = DeviceTraversal(idx, Q, nts)
+            st = ShardedTraversal(local, allgather_for(rank), rank, world, nts, local_cap=nts)
+            sc, fr = st.run()
+            out[rank] = (sc, fr, st.rounds, [local.results(i) for i in range(5)])
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not errs, errs
+    # oracle lock-step reference of the same rounds
+    locals_ = [OracleLocalTraversal(oracle, g, X, Q, nts) for X, g in shards]
+    for l in locals_:
+        l.set_targets(np.full(5, -(-nts // world), np.uint64))
+    rounds = 0
+    while True:
+        [l.run() for l in locals_]
+        fs = [l.frontier() for l in locals_]
+        scm, frm = np.stack([f[1] for f in fs]), np.stack([f[0] for f in fs])
+        rounds += 1
+        tg, done = allocate_targets(scm, frm, nts, nts)
+        if done.all():
+            break
+        for r, l in enumerate(locals_):
+            l.set_targets(tg[r])
+    for r in range(world):
+        sc, fr, nr, res = out[r]
+        assert nr == rounds and np.array_equal(sc, scm) and np.array_equal(fr, frm)
+        for i in range(5):
+            for x, y in zip(res[i], locals_[r].results(i)):
+                assert np.array_equal(x, y)
+
+
+def test_rccl_comm_world1(gpu):
+    from rad_amd.device import RcclComm
+    uid = RcclComm.unique_id()
+    assert len(uid) == 128
+    c = RcclComm(0, 1, uid, 0)
+    a = np.arange(1000, dtype=np.uint64) * 3
+    out = c.allgather_u64(a)
+    assert out.shape == (1, 1000) and np.array_equal(out[0], a)
+    c.close()

@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--n-to-score", type=int, default=100_000)
     ap.add_argument("--corpus-mode", type=int, default=1, help="0 dense Bernoulli(0.5), 1 clustered sparse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-traversals", type=int, default=0, help="0 = 8 per host core")
+    ap.add_argument("--cpu-traversals", type=int, default=0, help="0 = 32 per host core")
     return ap.parse_args()
 
 
@@ -59,19 +59,27 @@ def main():
 
     dist = None
     if world > 1:
-        # torch is plumbing only: rendezvous, barrier, max-over-ranks
+        # torch is plumbing only: rendezvous (gloo), barrier, max-over-ranks, and handing the
+        # RCCL unique id of the library's own communicator to the other ranks
         import torch
         import torch.distributed as dist_mod
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist_mod.init_process_group(backend="gloo")
         dist = dist_mod
 
     from rad_amd import _lib
-    from rad_amd.device import DeviceIndex, DeviceTraversal
+    from rad_amd.device import DeviceIndex, DeviceTraversal, RcclComm
+    from rad_amd.sharded import ShardedTraversal
 
     _lib.lib()
     if _lib.device_count() <= local_rank:
         raise SystemExit("bench.py needs an MI355X per rank; there is no CPU fallback")
+
+    comm = None
+    if dist is not None:
+        box = [RcclComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = RcclComm(rank, world, box[0], local_rank)
 
     def barrier_sync():
         if dist is not None:
@@ -95,12 +103,22 @@ def main():
     for b in range(n_batches):
         first = int(qrng.integers(0, n - args.nq))
         batches.append(idx.read_vectors(first, args.nq))
-    trav = DeviceTraversal(idx, batches[0], args.n_to_score)
+    # sharded: the global budget is world x n_to_score, split over the shards round by round
+    # (rad_amd/sharded.py); the local state is sized with 25 % headroom over the even split
+    local_cap = args.n_to_score if world == 1 else args.n_to_score + args.n_to_score // 4
+    trav = DeviceTraversal(idx, batches[0], local_cap)
+    exch = {"rounds": 0, "bytes": 0}
 
     def step(b):
         trav.reset(batches[b])
-        running = trav.run(0)
-        assert running == 0
+        if comm is None:
+            running = trav.run(0)
+            assert running == 0
+        else:
+            st_ = ShardedTraversal(trav, comm.allgather_u64, rank, world, args.n_to_score * world, local_cap)
+            st_.run()
+            exch["rounds"] += st_.rounds
+            exch["bytes"] += st_.exchanged_bytes
         ms, launches = trav.kernel_time()
         st = trav.stats()
         return ms, launches, int(st.n_pops.sum()), int(st.n_scored.sum()), int(st.n_nbr.sum())
@@ -125,7 +143,7 @@ def main():
     tot = np.array([elapsed, float(pops), float(evals), k_ms, float(k_launches)], dtype=np.float64)
     if dist is not None:
         import torch
-        tt = torch.tensor(tot, device="cuda")
+        tt = torch.tensor(tot)
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone()
@@ -176,7 +194,10 @@ def main():
                         f"to n_to_score={args.n_to_score}, synthetic corpus+graph",
             "rows_per_gpu": n, "ndim": ndim, "connectivity": M, "nq_per_gpu": args.nq,
             "n_to_score": args.n_to_score, "corpus_mode": args.corpus_mode,
-            "parallelism": "1 process per GPU, corpus sharded by contiguous row range" if world > 1 else "single GPU",
+            "parallelism": ("1 process per GPU, corpus sharded by contiguous row range, global n_to_score = "
+                            f"{world} x {args.n_to_score} split over shards by per-round RCCL all-gather of frontier "
+                            "scores + scored counts") if world > 1 else "single GPU",
+            "exchange_rounds_per_step": (exch["rounds"] / max(args.steps + args.warmup, 1)) if world > 1 else 0,
         },
         "evals_per_s": evals_all / elapsed_max,
         "evals_per_expansion": evals_all / max(pops_all, 1.0),
@@ -197,13 +218,26 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores() -> int:
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(idx, queries, args):
     """The oracle (C restatement of the reference control flow, pthreads over independent
     traversals) timed on this box's host cores, on a bounded sample of the same workload:
     same corpus + graph (copied back from HBM), same n_to_score, fewer traversals."""
     from oracle import rad_oracle as O
     O.build()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     info = idx.info()
     n = info.n
     X = np.empty((n, idx.row_bytes), np.uint8)
@@ -214,7 +248,7 @@ def cpu_baseline(idx, queries, args):
     levels, adj0, upper_row, adjU = idx.read_graph()
     g = O.Graph(int(n), int(info.connectivity_base), int(info.connectivity), int(info.max_level),
                 int(info.entry), levels, adj0, upper_row, adjU)
-    nt = args.cpu_traversals or 8 * cores
+    nt = args.cpu_traversals or 32 * cores
     nt = min(nt, queries.shape[0])
     t0 = time.perf_counter()
     n_scored, n_pops, n_nbr = O.rad_traverse_many(g, X, queries[:nt], args.n_to_score, cores)

@@ -82,12 +82,51 @@ __device__ __forceinline__ uint32_t rh_popc4(const uint4 v) {
 __device__ __forceinline__ uint32_t rh_popc4_and(const uint4 a, const uint4 b) {
     return __popc(a.x & b.x) + __popc(a.y & b.y) + __popc(a.z & b.z) + __popc(a.w & b.w);
 }
-// sum over groups of LPR adjacent lanes; every lane of the group gets the total
+// ---- DPP cross-lane helpers (no LDS traffic, unlike __shfl/ds_bpermute) ---------------
+#define RH_DPP_QUAD_XOR1 0xB1     /* quad_perm:[1,0,3,2] */
+#define RH_DPP_QUAD_XOR2 0x4E     /* quad_perm:[2,3,0,1] */
+#define RH_DPP_ROW_HALF_MIRROR 0x141
+#define RH_DPP_ROW_MIRROR 0x140
+#define RH_DPP_ROW_SHR(n) (0x110 + (n))
+#define RH_DPP_ROW_BCAST15 0x142
+#define RH_DPP_ROW_BCAST31 0x143
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t rh_dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+// sum over groups of LPR adjacent lanes (LPR = 1,2,4,8,16); every lane of the group gets
+// the total.  Butterfly: xor1, xor2 inside quads, then half-row and row mirrors.
 template <int LPR>
 __device__ __forceinline__ uint32_t rh_group_sum(uint32_t v) {
-#pragma unroll
-    for (int m = 1; m < LPR; m <<= 1) v += __shfl_xor(v, m, RH_WAVE);
+    if (LPR >= 2) v += rh_dpp<RH_DPP_QUAD_XOR1>(v);
+    if (LPR >= 4) v += rh_dpp<RH_DPP_QUAD_XOR2>(v);
+    if (LPR >= 8) v += rh_dpp<RH_DPP_ROW_HALF_MIRROR>(v);
+    if (LPR >= 16) v += rh_dpp<RH_DPP_ROW_MIRROR>(v);
     return v;
+}
+// wave-wide unsigned min, result uniform (read from lane 63 after a row scan + row broadcasts)
+__device__ __forceinline__ uint32_t rh_wave_min_u32(uint32_t v) {
+#define RH_MIN_STEP(CTRL, ROWMASK)                                                              \
+    {                                                                                           \
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, CTRL, ROWMASK, 0xf, false); \
+        v = o < v ? o : v;                                                                      \
+    }
+    RH_MIN_STEP(RH_DPP_ROW_SHR(1), 0xf)
+    RH_MIN_STEP(RH_DPP_ROW_SHR(2), 0xf)
+    RH_MIN_STEP(RH_DPP_ROW_SHR(4), 0xf)
+    RH_MIN_STEP(RH_DPP_ROW_SHR(8), 0xf)
+    RH_MIN_STEP(RH_DPP_ROW_BCAST15, 0xa)
+    RH_MIN_STEP(RH_DPP_ROW_BCAST31, 0xc)
+#undef RH_MIN_STEP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// wave-wide min of u64 keys (two u32 passes: high words, then low words among the ties)
+__device__ __forceinline__ unsigned long long rh_wave_min_u64(unsigned long long k) {
+    const uint32_t hi = (uint32_t)(k >> 32), lo = (uint32_t)k;
+    const uint32_t mhi = rh_wave_min_u32(hi);
+    const uint32_t mlo = rh_wave_min_u32(hi == mhi ? lo : 0xFFFFFFFFu);
+    return ((unsigned long long)mhi << 32) | mlo;
 }
 
 // ---------------------------------------------------- RAD queue key (u64) --

@@ -170,7 +170,10 @@ typedef struct {
     uint64_t n_scored;   /* nodes in the scored set (== Tanimoto evaluations) */
     uint64_t n_pops;     /* node expansions                                   */
     uint64_t n_nbr;      /* adjacency entries examined                        */
+    uint64_t n_repivot;  /* queue maintenance: pivot raises (far -> registers)    */
+    uint64_t n_flush;    /* queue maintenance: staging flushes (sorted runs)     */
     int32_t status;      /* 0 running, 1 done(n_to_score), 2 done(queue empty),
+                            3 parked at an intermediate target,
                             negative RADHIP_E_* on a device-side failure       */
     int32_t reserved;
 } radhip_trav_stats_t;

@@ -36,6 +36,7 @@ class IndexInfo(C.Structure):
 
 class TravStats(C.Structure):
     _fields_ = [("n_scored", C.c_uint64), ("n_pops", C.c_uint64), ("n_nbr", C.c_uint64),
+                ("n_repivot", C.c_uint64), ("n_flush", C.c_uint64),
                 ("status", C.c_int32), ("reserved", C.c_int32)]
 
 

@@ -1,5 +1,5 @@
 // traverse.hip — K3: RAD best-first traversal, Tanimoto-scored, one wavefront
-// per traversal.  gfx950 only (wave64, LDS, no MFMA: this is bit counting).
+// per traversal.  gfx950 only (wave64, LDS, DPP; no MFMA: this is bit counting).
 //
 // Reference control flow restated on the device (paths relative to the
 // reference tree):
@@ -12,13 +12,19 @@
 //   queue insert/descend  rad/coordination_service.py:369-395
 //
 // Per-traversal state lives in HBM (sized for n_to_score):
-//   ht      open-addressing table {slot, and|or<<12|v0<<24}: presence == scored,
-//           v0 == visited on level 0
+//   ht      open-addressing table of u64 {slot | (and|or<<12|v0<<24)<<32}: presence ==
+//           scored, v0 == visited on level 0
 //   ut      open-addressing set of (slot<<4|level)+1 for levels >= 1
 //   scored  {slot, and|or<<16} in insertion order (the output)
-//   pq      sorted runs of u64 keys, written once by staging flushes
-// and in LDS while the kernel runs:
-//   staging unsorted recent inserts (S_CAP keys), run heads (MAX_RUNS)
+//   pq      "far" keys: sorted runs of u64 keys written once by staging flushes, with a
+//           run table {pos,end} and the head key of every run
+// The queue is a two-level "pivot queue":
+//   near    every key below `pivot` lives in registers: RK sorted keys per lane (lane-private
+//           insertion is SIMD-parallel, pop-min is one DPP wave-min)
+//   far     keys >= pivot are appended unsorted to LDS staging (S_CAP keys) and flushed as
+//           sorted runs; they are not looked at again until the near set runs dry, when the
+//           pivot is raised and the run prefixes / staging keys below it move to registers.
+//   Invariant: every far key >= pivot, so a near key below the pivot is the global minimum.
 #include "common.h"
 
 #include <algorithm>
@@ -28,18 +34,20 @@
 #define RH_S_CAP 512
 #endif
 #ifndef RH_MAX_RUNS
-#define RH_MAX_RUNS 512
+#define RH_MAX_RUNS 2048
 #endif
 #define S_CAP ((uint32_t)RH_S_CAP)
 #define MAX_RUNS ((uint32_t)RH_MAX_RUNS)
+#define RK 4
 #define HT_EMPTY64 0xFFFFFFFFFFFFFFFFull
 #define VAL_V0 (1u << 24)
 #define VAL_PENDING 0xFFFFFFFEu
+#define DQ_INIT (1u << 14)
+#define DQ_MAX (1u << 23)
 
-// One wave per workgroup: LDS traffic of a single wave is executed in issue
-// order, so cross-lane hand-offs through LDS need only a compiler barrier — not
-// the s_waitcnt vmcnt(0) that __syncthreads() adds (it would stall on every
-// outstanding global store).
+// One wave per workgroup: LDS traffic of a single wave is executed in issue order, so
+// cross-lane hand-offs through LDS need only a compiler barrier — not the
+// s_waitcnt vmcnt(0) that __syncthreads() adds (it would stall on every outstanding store).
 #define WSYNC()                                                  \
     do {                                                         \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
@@ -51,7 +59,10 @@ struct TravHeader {
     uint64_t n_scored, n_pops, n_nbr, pq_used, n_upper;
     uint64_t target;        // stop once n_scored >= target (checked before every pop)
     uint64_t frontier_key;  // best queue key when the kernel last returned (RH_KEY_INF = empty)
+    uint64_t pivot;
+    uint64_t n_repivot, n_flush;
     uint32_t stg_cnt, n_runs, qpop, primed;
+    uint32_t dq, pad0;
     int32_t status;
     uint32_t pad;
 };
@@ -61,6 +72,7 @@ struct TravParams {
     const uint32_t *adj0, *upper_row, *adjU, *top;
     uint32_t n_top, cap0, capU, nq;
     int32_t start_level;
+    uint32_t spread_shift;   // new keys of an expansion go to lanes (i << spread_shift) + rot
     uint64_t n_to_score, max_pops;
     TravHeader *hdr;
     const uint4 *queries;
@@ -73,22 +85,15 @@ struct TravParams {
     unsigned long long *pq;
     uint64_t pq_cap;
     unsigned long long *stg_save;  // [nq * S_CAP]
-    uint2 *runs_save;              // [nq * MAX_RUNS] {pos, end}
+    unsigned long long *r_save;    // [nq * RK * 64] near keys
+    uint2 *runs;                   // [nq * MAX_RUNS] {pos, end}
+    unsigned long long *rhead;     // [nq * MAX_RUNS] head key of every run (INF = exhausted)
     uint32_t *poplog_nodes;
     uint8_t *poplog_levels;
     uint64_t poplog_cap;
 };
 
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        unsigned long long o = __shfl_xor(v, m, RH_WAVE);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-
-__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t *p) {
+__device__ __forceinline__ unsigned long long ld64(const unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st_relaxed(uint32_t *p, uint32_t v) {
@@ -97,10 +102,11 @@ __device__ __forceinline__ void st_relaxed(uint32_t *p, uint32_t v) {
 
 struct TravLds {
     unsigned long long stg[S_CAP];
-    unsigned long long rkey[MAX_RUNS];
     uint32_t new_slot[64];
+    uint32_t new_h[64];
     uint32_t new_and[64];
     uint32_t new_or[64];
+    uint32_t claim[256];
 };
 
 // ascending in-place bitonic sort of s[0..P), P a power of two, by one wave
@@ -119,6 +125,34 @@ __device__ void lds_bitonic_sort(unsigned long long *s, uint32_t P, uint32_t lan
     }
 }
 
+// insert x into the lane's sorted keys k0<=k1<=k2<=k3 (RH_KEY_INF = free); returns the key that
+// fell off the end (the largest of the five), RH_KEY_INF if there was room or x was INF
+__device__ __forceinline__ unsigned long long r_insert(unsigned long long x, unsigned long long &k0,
+                                                       unsigned long long &k1, unsigned long long &k2,
+                                                       unsigned long long &k3) {
+    unsigned long long t = x, a;
+    if (t < k0) { a = k0; k0 = t; t = a; }
+    if (t < k1) { a = k1; k1 = t; t = a; }
+    if (t < k2) { a = k2; k2 = t; t = a; }
+    if (t < k3) { a = k3; k3 = t; t = a; }
+    return t;
+}
+
+__device__ __forceinline__ uint32_t key_slot(unsigned long long key) {
+    const uint32_t p1 = ((uint32_t)(key >> 8) & 0x3FFFFFFFu) + 1u;
+    switch ((uint32_t)(key >> 4) & 0xFu) {   // wave-uniform at the only call site
+        case 0: return p1 - 1u;
+        case 1: return p1 / 10u - 1u;
+        case 2: return p1 / 100u - 1u;
+        case 3: return p1 / 1000u - 1u;
+        case 4: return p1 / 10000u - 1u;
+        case 5: return p1 / 100000u - 1u;
+        case 6: return p1 / 1000000u - 1u;
+        case 7: return p1 / 10000000u - 1u;
+        default: return p1 / 100000000u - 1u;
+    }
+}
+
 template <int LPR>
 __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
     __shared__ TravLds L;
@@ -130,11 +164,12 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
     if (status != 0) return;
 
     uint64_t n_scored = H->n_scored, n_pops = H->n_pops, n_nbr = H->n_nbr, pq_used = H->pq_used,
-             n_upper = H->n_upper;
-    uint32_t cnt = H->stg_cnt, n_runs = H->n_runs;
+             n_upper = H->n_upper, n_repivot = H->n_repivot, n_flush = H->n_flush;
+    uint32_t cnt = H->stg_cnt, n_runs = H->n_runs, dq = H->dq;
     const uint32_t qpop = H->qpop;
     uint32_t primed = H->primed;
     const uint64_t target = H->target;
+    unsigned long long pivot = H->pivot;
 
     unsigned long long *ht = P.ht + ((uint64_t)q << P.ht_log2);
     const uint32_t ht_shift = 32u - P.ht_log2;
@@ -145,107 +180,204 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
     const uint64_t ut_limit = ((uint64_t)1 << P.ut_log2) - ((uint64_t)1 << P.ut_log2) / 4;
     uint2 *scored = P.scored + (uint64_t)q * P.scored_cap;
     unsigned long long *pq = P.pq + (uint64_t)q * P.pq_cap;
+    uint2 *runs = P.runs + (uint64_t)q * MAX_RUNS;
+    unsigned long long *rhead = P.rhead + (uint64_t)q * MAX_RUNS;
     const uint32_t chunk = lane % LPR;
     const uint4 qv = P.queries[(uint64_t)q * LPR + chunk];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    // ---- restore LDS state ------------------------------------------------
-    for (uint32_t i = lane; i < cnt; i += 64) L.stg[i] = P.stg_save[(uint64_t)q * S_CAP + i];
-    uint2 *runs = P.runs_save + (uint64_t)q * MAX_RUNS;  // {pos, end} of every run, live in HBM
-    for (uint32_t r = lane; r < n_runs; r += 64) {
-        const uint2 pe = runs[r];
-        L.rkey[r] = pe.x < pe.y ? pq[pe.x] : RH_KEY_INF;
+    // ---- restore near keys + staging -----------------------------------------
+    unsigned long long k0 = RH_KEY_INF, k1 = RH_KEY_INF, k2 = RH_KEY_INF, k3 = RH_KEY_INF;
+    if (primed) {
+        const unsigned long long *rs = P.r_save + (uint64_t)q * (RK * 64);
+        k0 = rs[lane]; k1 = rs[64 + lane]; k2 = rs[128 + lane]; k3 = rs[192 + lane];
     }
+    for (uint32_t i = lane; i < cnt; i += 64) L.stg[i] = P.stg_save[(uint64_t)q * S_CAP + i];
     WSYNC();
 
-    // ---- flush staging into a new sorted run --------------------------------
+    // ---- far: append keys (one per lane where `has`) to staging ----------------
+    auto far_append = [&](bool has, unsigned long long key) {
+        const unsigned long long b = __ballot(has);
+        if (b) {
+            const uint32_t r = (uint32_t)__popcll(b & lt_mask);
+            if (has) L.stg[cnt + r] = key;
+            cnt += (uint32_t)__popcll(b);
+            WSYNC();
+        }
+    };
+
+    // ---- far: flush staging into a new sorted run --------------------------------
     auto flush = [&]() {
         if (cnt == 0) return;
+        if (n_runs >= MAX_RUNS || pq_used + cnt > P.pq_cap) { status = RADHIP_E_CAPACITY; return; }
         uint32_t Pw = 2;
         while (Pw < cnt) Pw <<= 1;
         for (uint32_t i = cnt + lane; i < Pw; i += 64) L.stg[i] = RH_KEY_INF;
         WSYNC();
         lds_bitonic_sort(L.stg, Pw, lane);
-        // pick a run slot: reuse an exhausted one, else append
-        uint32_t r = n_runs;
-        for (uint32_t base = 0; base < n_runs; base += 64) {
-            const uint32_t i = base + lane;
-            const bool dead = i < n_runs && L.rkey[i] == RH_KEY_INF;
-            const unsigned long long b = __ballot(dead);
-            if (b) { r = base + (uint32_t)__ffsll((unsigned long long)b) - 1u; break; }
-        }
-        if ((r == n_runs && n_runs >= MAX_RUNS) || pq_used + cnt > P.pq_cap) {
-            status = RADHIP_E_CAPACITY;
-            return;
-        }
         for (uint32_t i = lane; i < cnt; i += 64) pq[pq_used + i] = L.stg[i];
         if (lane == 0) {
-            runs[r] = make_uint2((uint32_t)pq_used, (uint32_t)(pq_used + cnt));
-            L.rkey[r] = L.stg[0];
+            runs[n_runs] = make_uint2((uint32_t)pq_used, (uint32_t)(pq_used + cnt));
+            rhead[n_runs] = L.stg[0];
         }
-        if (r == n_runs) n_runs++;
+        n_runs++;
+        n_flush++;
         pq_used += cnt;
         cnt = 0;
-        __threadfence_block();  // run keys + {pos,end} are re-read by this wave later
+        __threadfence_block();  // run keys, {pos,end} and head are re-read by this wave later
         WSYNC();
     };
 
-    // ---- visited / scored / evaluate / enqueue for up to 64 candidate slots --
-    // (one per lane, distinct).  `prime` keeps the reference's unconditional
-    // queue insert of rad/traverser.py:158-168.
-    auto process = [&](uint32_t slot, bool valid, uint32_t level, bool prime) {
-        bool go = valid;
-        if (level > 0 && go) {
-            const unsigned long long k1 = (((unsigned long long)slot << 4) | level) + 1ull;
-            uint32_t h = (uint32_t)((k1 * 0x9E3779B97F4A7C15ull) >> ut_shift);
-            bool fresh = false;
-            for (;;) {
-                const unsigned long long old = atomicCAS(&ut[h], 0ull, k1);
-                if (old == 0ull) { fresh = true; break; }
-                if (old == k1) break;
-                h = (h + 1u) & ut_mask;
+    // ---- raise the pivot and move every far key below it into registers ---------------
+    auto repivot = [&]() {
+        n_repivot++;
+        if (cnt + 130u > S_CAP) { flush(); if (status) return; }
+        unsigned long long fm = RH_KEY_INF;
+        for (uint32_t i = lane; i < cnt; i += 64) { const unsigned long long v = L.stg[i]; fm = v < fm ? v : fm; }
+        for (uint32_t r = lane; r < n_runs; r += 64) { const unsigned long long v = ld64(&rhead[r]); fm = v < fm ? v : fm; }
+        fm = rh_wave_min_u64(fm);
+        if (fm == RH_KEY_INF) { pivot = RH_KEY_INF; return; }   // far is empty
+        const uint64_t nqv = (fm >> 38) + (uint64_t)dq;
+        pivot = nqv >= (1ull << 24) ? RH_KEY_INF : (nqv << 38);
+        unsigned long long newpiv = RH_KEY_INF;  // lane-private: smallest key this lane left in far below the pivot
+        unsigned long long rej1 = RH_KEY_INF;    // at most one displaced near key per lane (goes to staging)
+        // staging: a taken key leaves its slot; a displaced near key takes the slot over
+        bool any_taken = false;
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            const uint32_t i = base + lane;
+            const unsigned long long v = i < cnt ? L.stg[i] : RH_KEY_INF;
+            if (v < pivot) {
+                if (k3 == RH_KEY_INF) { (void)r_insert(v, k0, k1, k2, k3); L.stg[i] = RH_KEY_INF; any_taken = true; }
+                else if (v < k3) {
+                    const unsigned long long rj = r_insert(v, k0, k1, k2, k3);
+                    L.stg[i] = rj;
+                    newpiv = rj < newpiv ? rj : newpiv;
+                } else newpiv = v < newpiv ? v : newpiv;
             }
-            go = fresh || prime;
         }
+        WSYNC();
+        if (__ballot(any_taken)) {   // squeeze the holes out of staging
+            uint32_t w = 0;
+            for (uint32_t base = 0; base < cnt; base += 64) {
+                const uint32_t i = base + lane;
+                const unsigned long long v = i < cnt ? L.stg[i] : RH_KEY_INF;
+                const bool keep = v != RH_KEY_INF;
+                const unsigned long long b = __ballot(keep);
+                if (keep) L.stg[w + (uint32_t)__popcll(b & lt_mask)] = v;
+                w += (uint32_t)__popcll(b);
+                WSYNC();
+            }
+            cnt = w;
+        }
+        // runs: lane l owns runs l, l+64, ...; a run gives up its prefix below the pivot
+        for (uint32_t r = lane; r < n_runs; r += 64) {
+            unsigned long long h = ld64(&rhead[r]);
+            if (h >= pivot) continue;
+            const unsigned long long pe64 = ld64(reinterpret_cast<const unsigned long long *>(&runs[r]));
+            uint2 pe = make_uint2((uint32_t)pe64, (uint32_t)(pe64 >> 32));
+            while (h < pivot) {
+                if (k3 != RH_KEY_INF) {
+                    if (h < k3 && rej1 == RH_KEY_INF) rej1 = r_insert(h, k0, k1, k2, k3);
+                    else { newpiv = h < newpiv ? h : newpiv; break; }
+                } else (void)r_insert(h, k0, k1, k2, k3);
+                pe.x++;
+                h = pe.x < pe.y ? ld64(&pq[pe.x]) : RH_KEY_INF;
+            }
+            runs[r] = pe;
+            rhead[r] = h;
+        }
+        newpiv = rej1 < newpiv ? rej1 : newpiv;
+        const unsigned long long np = rh_wave_min_u64(newpiv);
+        const bool crowded = np != RH_KEY_INF;
+        pivot = np < pivot ? np : pivot;
+        far_append(rej1 != RH_KEY_INF, rej1);
+        // adapt the pivot step to keep the registers about half full
+        const uint32_t occ = (uint32_t)__popcll(__ballot(k0 != RH_KEY_INF)) + (uint32_t)__popcll(__ballot(k1 != RH_KEY_INF)) +
+                             (uint32_t)__popcll(__ballot(k2 != RH_KEY_INF)) + (uint32_t)__popcll(__ballot(k3 != RH_KEY_INF));
+        if (crowded) dq = dq > 1u ? dq >> 1 : 1u;
+        else if (occ < 96u) dq = dq < DQ_MAX ? dq << 1 : DQ_MAX;
+    };
+
+    // ---- enqueue one key per lane where `push` ---------------------------------------------
+    auto enqueue = [&](bool push, unsigned long long key) {
+        const bool near = push && key < pivot;
+        const unsigned long long rej = r_insert(near ? key : RH_KEY_INF, k0, k1, k2, k3);
+        const bool rj = rej != RH_KEY_INF;
+        if (__ballot(rj)) {   // a full lane pushed its largest key out: it becomes a far key
+            const unsigned long long m = rh_wave_min_u64(rej);
+            pivot = m < pivot ? m : pivot;
+            far_append(rj, rej);
+        }
+        far_append(push && !near, key);
+    };
+
+    // ---- visited / scored / evaluate / enqueue for up to 64 candidate slots (one per lane,
+    // distinct).  `prime` keeps the reference's unconditional queue insert (rad/traverser.py:158-168).
+    auto process = [&](uint32_t slot, bool valid, uint32_t level, bool prime, uint32_t rot) {
+        bool go = valid;
         if (level > 0) {
-            // every lane that is still `go` inserted a fresh (slot, level) entry
+            if (go) {
+                const unsigned long long kk = (((unsigned long long)slot << 4) | level) + 1ull;
+                uint32_t h = (uint32_t)((kk * 0x9E3779B97F4A7C15ull) >> ut_shift);
+                bool fresh = false;
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&ut[h], 0ull, kk);
+                    if (old == 0ull) { fresh = true; break; }
+                    if (old == kk) break;
+                    h = (h + 1u) & ut_mask;
+                }
+                go = fresh || prime;
+            }
             n_upper += (uint64_t)__popcll(__ballot(go));
             if (n_upper > ut_limit) { status = RADHIP_E_CAPACITY; return; }
         }
+        // Probe with plain (L2-served) loads: the table belongs to this wave alone, so the only
+        // race is two lanes of THIS expansion wanting the same empty bucket — settled through an
+        // LDS claim word.  No atomics reach HBM (they execute memory-side and capped v1).
         bool isnew = false;
         uint32_t h = 0, val = 0;
-        if (go) {
-            // one 64-bit CAS both claims an empty bucket and returns the stored
-            // value of a present node: a single L2 round trip per probe
-            const unsigned long long mine = (unsigned long long)slot | ((unsigned long long)VAL_PENDING << 32);
-            h = (slot * 2654435769u) >> ht_shift;
+        {
+            bool pending = go;          // still walking the probe sequence
+            bool cand = false;          // stopped at an empty bucket, not yet confirmed
+            if (go) h = (slot * 2654435769u) >> ht_shift;
             for (;;) {
-                const unsigned long long old = atomicCAS(&ht[h], HT_EMPTY64, mine);
-                if (old == HT_EMPTY64) { isnew = true; break; }
-                if ((uint32_t)old == slot) { val = (uint32_t)(old >> 32); break; }
-                h = (h + 1u) & ht_mask;
+                if (pending) {
+                    for (;;) {
+                        const unsigned long long e = ld64(&ht[h]);
+                        if (e == HT_EMPTY64) { cand = true; break; }
+                        if ((uint32_t)e == slot) { val = (uint32_t)(e >> 32); break; }
+                        h = (h + 1u) & ht_mask;
+                    }
+                    pending = false;
+                }
+                if (!__ballot(cand)) break;
+                const uint32_t tag = (h << 6) | lane;
+                if (cand) L.claim[h & 255u] = tag;
+                WSYNC();
+                const uint32_t got = cand ? L.claim[h & 255u] : 0u;
+                WSYNC();
+                if (cand) {
+                    if (got == tag) { isnew = true; cand = false; }                    // bucket is mine
+                    else if ((got >> 6) == h) { cand = false; pending = true; h = (h + 1u) & ht_mask; }  // lost it
+                    // else: another bucket shares the claim word — ask again next round
+                }
             }
         }
-        uint32_t *const vptr = reinterpret_cast<uint32_t *>(&ht[h]) + 1;
-        uint32_t a = 0, o = 0;
-        bool push = false;
+        // scored before: re-enqueue on this level unless already visited here
+        bool push_old = false;
         if (go && !isnew) {
-            a = val & 0xFFFu;
-            o = (val >> 12) & 0xFFFu;
             if (level == 0) {
                 if (!(val & VAL_V0) || prime) {
-                    st_relaxed(vptr, val | VAL_V0);
-                    push = true;
+                    st_relaxed(reinterpret_cast<uint32_t *>(&ht[h]) + 1, val | VAL_V0);
+                    push_old = true;
                 }
-            } else {
-                push = true;
-            }
+            } else push_old = true;
         }
         const unsigned long long nb = __ballot(isnew);
         const uint32_t nn = (uint32_t)__popcll(nb);
-        const uint32_t rank = (uint32_t)__popcll(nb & lt_mask);
         if (nn) {
-            if (isnew) L.new_slot[rank] = slot;
+            const uint32_t rank = (uint32_t)__popcll(nb & lt_mask);
+            if (isnew) { L.new_slot[rank] = slot; L.new_h[rank] = h; }
             WSYNC();
             constexpr uint32_t RPP = 64 / LPR;  // rows per pass
             for (uint32_t base = 0; base < nn; base += RPP) {
@@ -254,40 +386,43 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
                 if (ri < nn) v = P.fp[(uint64_t)L.new_slot[ri] * LPR + chunk];
                 const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v));
                 const uint32_t aa = rh_group_sum<LPR>(rh_popc4_and(v, qv));
-                if (ri < nn && chunk == 0) {
-                    L.new_and[ri] = aa;
-                    L.new_or[ri] = qpop + rp - aa;
-                }
+                if (ri < nn && chunk == 0) { L.new_and[ri] = aa; L.new_or[ri] = qpop + rp - aa; }
             }
             WSYNC();
-            if (isnew) {
-                a = L.new_and[rank];
-                o = L.new_or[rank];
-                st_relaxed(vptr, a | (o << 12) | (level == 0 ? VAL_V0 : 0u));
-                scored[n_scored + rank] = make_uint2(slot, a | (o << 16));
-                push = true;
+            // finish the new nodes on lanes spread over the wave (so their keys land in
+            // different lanes' registers): new index ni -> lane (ni << sh) + rot
+            const uint32_t sh = (nn << P.spread_shift) <= 64u ? P.spread_shift : 0u;
+            const uint32_t u = (lane - rot) & 63u;
+            const uint32_t ni = u >> sh;
+            const bool mine = ((u & ((1u << sh) - 1u)) == 0u) && ni < nn;
+            unsigned long long key = RH_KEY_INF;
+            if (mine) {
+                const uint32_t s2 = L.new_slot[ni], a = L.new_and[ni], o = L.new_or[ni];
+                __hip_atomic_store(&ht[L.new_h[ni]], (unsigned long long)s2 | ((unsigned long long)(a | (o << 12) | (level == 0 ? VAL_V0 : 0u)) << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                scored[n_scored + ni] = make_uint2(s2, a | (o << 16));
+                key = rh_make_key(rh_q24(a, o), s2, level);
             }
             n_scored += nn;
+            enqueue(mine, key);
         }
-        // enqueue
-        const unsigned long long pb = __ballot(push);
-        if (pb) {
-            const uint32_t pr = (uint32_t)__popcll(pb & lt_mask);
-            if (push) L.stg[cnt + pr] = rh_make_key(rh_q24(a, o), slot, level);
-            cnt += (uint32_t)__popcll(pb);
+        if (__ballot(push_old)) {
+            unsigned long long key = RH_KEY_INF;
+            if (push_old) key = rh_make_key(rh_q24(val & 0xFFFu, (val >> 12) & 0xFFFu), slot, level);
+            enqueue(push_old, key);
         }
-        WSYNC();
     };
 
     // ---- prime ---------------------------------------------------------------
     if (!primed) {
+        pivot = RH_KEY_INF;   // far is empty: everything is near until a lane overflows
         for (uint32_t base = 0; base < P.n_top && status == 0; base += 64) {
-            if (cnt + 65u > S_CAP) flush();
+            if (cnt + 130u > S_CAP) flush();
             if (status) break;
             const uint32_t i = base + lane;
             const bool valid = i < P.n_top;
             const uint32_t slot = valid ? P.top[i] : RADHIP_NO_SLOT;
-            process(slot, valid, (uint32_t)P.start_level, true);
+            process(slot, valid, (uint32_t)P.start_level, true, 0u);
         }
         primed = 1;
     }
@@ -297,38 +432,21 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
     while (status == 0) {
         if (n_scored >= target) { status = target >= P.n_to_score ? 1 : 3; break; }
         if (P.max_pops && pops_here >= P.max_pops) break;
-        if (cnt + 66u > S_CAP) { flush(); if (status) break; }
-        // pop-min over staging and run heads
-        unsigned long long best = RH_KEY_INF;
-        uint32_t src = 0;
-        for (uint32_t i = lane; i < cnt; i += 64) {
-            const unsigned long long k = L.stg[i];
-            if (k < best) { best = k; src = i; }
+        if (cnt + 130u > S_CAP) { flush(); if (status) break; }
+        // pop-min: near keys below the pivot are globally minimal
+        unsigned long long mk = rh_wave_min_u64(k0);
+        if (mk >= pivot) {
+            if (mk == RH_KEY_INF && pivot == RH_KEY_INF && cnt == 0 && n_runs == 0) { status = 2; break; }
+            repivot();
+            if (status) break;
+            mk = rh_wave_min_u64(k0);
+            if (mk == RH_KEY_INF) { status = 2; break; }   // near and far both empty
+            if (mk >= pivot) continue;                      // pivot was lowered below the near minimum
         }
-        for (uint32_t r = lane; r < n_runs; r += 64) {
-            const unsigned long long k = L.rkey[r];
-            if (k < best) { best = k; src = 0x80000000u | r; }
-        }
-        const unsigned long long mk = wave_min_u64(best);
-        if (mk == RH_KEY_INF) { status = 2; break; }
-        const unsigned long long wb = __ballot(best == mk);
-        const int win = __ffsll((unsigned long long)wb) - 1;
-        const uint32_t wsrc = __shfl(src, win, RH_WAVE);
-        if (wsrc & 0x80000000u) {
-            const uint32_t r = wsrc & 0x7FFFFFFFu;
-            if (lane == 0) {
-                uint2 pe = runs[r];
-                pe.x += 1u;
-                runs[r] = pe;
-                L.rkey[r] = pe.x < pe.y ? pq[pe.x] : RH_KEY_INF;
-            }
-        } else {
-            if (lane == 0) L.stg[wsrc] = L.stg[cnt - 1u];
-            cnt--;
-        }
-        WSYNC();
-        uint32_t node, level;
-        rh_decode_key(mk, &node, &level);
+        const int win = __ffsll((unsigned long long)__ballot(k0 == mk)) - 1;
+        if ((int)lane == win) { k0 = k1; k1 = k2; k2 = k3; k3 = RH_KEY_INF; }
+        const uint32_t node = key_slot(mk);
+        const uint32_t level = rh_rank_level((uint32_t)mk & 0xFu);
         if (P.poplog_nodes && n_pops < P.poplog_cap && lane == 0) {
             P.poplog_nodes[(uint64_t)q * P.poplog_cap + n_pops] = node;
             P.poplog_levels[(uint64_t)q * P.poplog_cap + n_pops] = (uint8_t)level;
@@ -345,7 +463,7 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
         }
         const bool valid = nbr != RADHIP_NO_SLOT;
         n_nbr += (uint64_t)__popcll(__ballot(valid));
-        process(nbr, valid, level, false);
+        process(nbr, valid, level, false, (uint32_t)(n_pops * 7u) & 63u);
         if (status) break;
         // descend: same node, one level down, same score
         if (level > 0) {
@@ -353,12 +471,12 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
             bool push0 = false;
             if (lane == 0) {
                 if (nl > 0) {
-                    const unsigned long long k1 = (((unsigned long long)node << 4) | nl) + 1ull;
-                    uint32_t h = (uint32_t)((k1 * 0x9E3779B97F4A7C15ull) >> ut_shift);
+                    const unsigned long long kk = (((unsigned long long)node << 4) | nl) + 1ull;
+                    uint32_t h = (uint32_t)((kk * 0x9E3779B97F4A7C15ull) >> ut_shift);
                     for (;;) {
-                        const unsigned long long old = atomicCAS(&ut[h], 0ull, k1);
+                        const unsigned long long old = atomicCAS(&ut[h], 0ull, kk);
                         if (old == 0ull) { push0 = true; break; }
-                        if (old == k1) break;
+                        if (old == kk) break;
                         h = (h + 1u) & ut_mask;
                     }
                 } else {
@@ -375,30 +493,30 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
                         push0 = true;
                     }
                 }
-                if (push0) {
-                    const uint64_t qbits = mk >> 38;
-                    L.stg[cnt] = rh_make_key((uint32_t)qbits, node, nl);
-                }
             }
-            const bool p0 = __shfl((int)push0, 0, RH_WAVE) != 0;
-            if (p0) {
-                cnt++;
+            const bool any0 = __ballot(push0) != 0;
+            if (any0) {
                 if (nl > 0) n_upper++;
+                enqueue(push0, rh_make_key((uint32_t)(mk >> 38), node, nl));
             }
-            WSYNC();
         }
     }
 
     // ---- frontier score: best key left in the queue -------------------------------
-    unsigned long long fbest = RH_KEY_INF;
+    unsigned long long fbest = k0;
     for (uint32_t i = lane; i < cnt; i += 64) fbest = L.stg[i] < fbest ? L.stg[i] : fbest;
-    for (uint32_t r = lane; r < n_runs; r += 64) fbest = L.rkey[r] < fbest ? L.rkey[r] : fbest;
-    fbest = wave_min_u64(fbest);
+    for (uint32_t r = lane; r < n_runs; r += 64) { const unsigned long long v = ld64(&rhead[r]); fbest = v < fbest ? v : fbest; }
+    fbest = rh_wave_min_u64(fbest);
     // ---- persist ---------------------------------------------------------------
+    {
+        unsigned long long *rs = P.r_save + (uint64_t)q * (RK * 64);
+        rs[lane] = k0; rs[64 + lane] = k1; rs[128 + lane] = k2; rs[192 + lane] = k3;
+    }
     for (uint32_t i = lane; i < cnt; i += 64) P.stg_save[(uint64_t)q * S_CAP + i] = L.stg[i];
     if (lane == 0) {
         H->n_scored = n_scored; H->n_pops = n_pops; H->n_nbr = n_nbr; H->pq_used = pq_used;
         H->n_upper = n_upper; H->stg_cnt = cnt; H->n_runs = n_runs; H->primed = primed;
+        H->pivot = pivot; H->dq = dq; H->n_repivot = n_repivot; H->n_flush = n_flush;
         H->status = status;
         H->frontier_key = fbest;
     }
@@ -413,7 +531,7 @@ struct radhip_traversal {
     TravParams P{};
     uint4 *d_queries = nullptr;
     size_t ht_bytes = 0, ut_bytes = 0, scored_bytes = 0, pq_bytes = 0, stg_bytes = 0, runs_bytes = 0,
-           hdr_bytes = 0, log_bytes = 0;
+           rhead_bytes = 0, rsave_bytes = 0, hdr_bytes = 0, log_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0.0;
     uint64_t launches = 0;
@@ -438,6 +556,8 @@ static int trav_upload_queries(radhip_traversal *t, const uint8_t *queries) {
         hdr[i].qpop = p;
         hdr[i].target = t->n_to_score;
         hdr[i].frontier_key = RH_KEY_INF;
+        hdr[i].pivot = RH_KEY_INF;
+        hdr[i].dq = DQ_INIT;
     }
     RH_HIP(hipMemcpyAsync(t->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, idx->stream));
     RH_HIP(hipMemcpyAsync(t->P.hdr, hdr.data(), t->hdr_bytes, hipMemcpyHostToDevice, idx->stream));
@@ -459,7 +579,9 @@ extern "C" int radhip_traversal_destroy(radhip_traversal_t *t) {
     if (t->P.scored) (void)hipFree(t->P.scored);
     if (t->P.pq) (void)hipFree(t->P.pq);
     if (t->P.stg_save) (void)hipFree(t->P.stg_save);
-    if (t->P.runs_save) (void)hipFree(t->P.runs_save);
+    if (t->P.runs) (void)hipFree(t->P.runs);
+    if (t->P.rhead) (void)hipFree(t->P.rhead);
+    if (t->P.r_save) (void)hipFree(t->P.r_save);
     if (t->P.poplog_nodes) (void)hipFree(t->P.poplog_nodes);
     if (t->P.poplog_levels) (void)hipFree(t->P.poplog_levels);
     if (t->ev0) (void)hipEventDestroy(t->ev0);
@@ -498,6 +620,12 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     P.top = idx->d_top; P.n_top = idx->n_top; P.cap0 = idx->cap0; P.capU = idx->M; P.nq = nq;
     P.start_level = idx->max_level > 0 ? idx->max_level - 1 : 0;
     P.n_to_score = n_to_score; P.max_pops = 0;
+    {   // spread stride of new keys over the lanes: 64 / pow2ceil(widest adjacency row)
+        uint32_t w = std::max<uint32_t>(idx->cap0, idx->M), p2 = 1, sh = 6;
+        while (p2 < w) { p2 <<= 1; }
+        while ((p2 << sh) > 64u && sh > 0) sh--;
+        P.spread_shift = sh;
+    }
     P.ht_log2 = ht_log2; P.ut_log2 = ut_log2; P.scored_cap = scored_cap; P.pq_cap = pq_cap;
     t->hdr_bytes = (size_t)nq * sizeof(TravHeader);
     t->ht_bytes = ((size_t)nq << ht_log2) * 8;
@@ -506,6 +634,8 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     t->pq_bytes = (size_t)nq * pq_cap * 8;
     t->stg_bytes = (size_t)nq * S_CAP * 8;
     t->runs_bytes = (size_t)nq * MAX_RUNS * sizeof(uint2);
+    t->rhead_bytes = (size_t)nq * MAX_RUNS * 8;
+    t->rsave_bytes = (size_t)nq * RK * 64 * 8;
     int rc = RADHIP_OK;
 #define RH_A(ptr, bytes)                                                                   \
     do {                                                                                   \
@@ -522,7 +652,9 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     if (rc == 0) RH_A(P.scored, t->scored_bytes);
     if (rc == 0) RH_A(P.pq, t->pq_bytes);
     if (rc == 0) RH_A(P.stg_save, t->stg_bytes);
-    if (rc == 0) RH_A(P.runs_save, t->runs_bytes);
+    if (rc == 0) RH_A(P.runs, t->runs_bytes);
+    if (rc == 0) RH_A(P.rhead, t->rhead_bytes);
+    if (rc == 0) RH_A(P.r_save, t->rsave_bytes);
     if (rc == 0 && (flags & RADHIP_TRAV_LOG_POPS)) {
         P.poplog_cap = pq_cap;
         RH_A(P.poplog_nodes, (size_t)nq * P.poplog_cap * 4);
@@ -591,6 +723,7 @@ extern "C" int radhip_traversal_stats(const radhip_traversal_t *t, radhip_trav_s
     RH_HIP(hipMemcpy(hdr.data(), t->P.hdr, t->hdr_bytes, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < t->nq; ++i) {
         out[i].n_scored = hdr[i].n_scored; out[i].n_pops = hdr[i].n_pops; out[i].n_nbr = hdr[i].n_nbr;
+        out[i].n_repivot = hdr[i].n_repivot; out[i].n_flush = hdr[i].n_flush;
         out[i].status = hdr[i].status; out[i].reserved = 0;
     }
     return RADHIP_OK;

@@ -136,6 +136,8 @@ class TraversalStats:
     n_pops: np.ndarray
     n_nbr: np.ndarray
     status: np.ndarray
+    n_repivot: np.ndarray = None
+    n_flush: np.ndarray = None
 
 
 class DeviceTraversal:
@@ -181,7 +183,9 @@ class DeviceTraversal:
         return TraversalStats(np.array([s.n_scored for s in arr], np.int64),
                               np.array([s.n_pops for s in arr], np.int64),
                               np.array([s.n_nbr for s in arr], np.int64),
-                              np.array([s.status for s in arr], np.int32))
+                              np.array([s.status for s in arr], np.int32),
+                              np.array([s.n_repivot for s in arr], np.int64),
+                              np.array([s.n_flush for s in arr], np.int64))
 
     def results(self, q: int):
         """(slots, and, or) of traversal q in traversal order."""

@@ -35,5 +35,5 @@ for nts in [int(x) for x in a.nts.split(",")]:
         gbs = (ev * (B + 4) + pops * 4) / (ms * 1e-3) / 1e9
         print(f"nts={nts} nq={nq}: create {t4-t3:.2f}s wall {t5-t4:.3f}s kernel {ms:.2f} ms  pops={pops} evals={ev} nbr={nbr} "
               f"evals/pop={ev/pops:.2f} | {pops/ms/1e3:.2f} M exp/s {ev/ms/1e6:.3f} G eval/s  alg {gbs:.1f} GB/s ({gbs/8000*100:.1f}% of 8TB/s) "
-              f"state {t.state_bytes()/1e9:.2f} GB status={np.bincount(st.status+8)[8:]}", flush=True)
+              f"state {t.state_bytes()/1e9:.2f} GB status={np.bincount(st.status+8)[8:]} repivots/trav={st.n_repivot.mean():.0f} flushes/trav={st.n_flush.mean():.0f}", flush=True)
         t.close()

@@ -202,6 +202,9 @@ int radhip_traversal_pop_log(const radhip_traversal_t *t, uint32_t q, uint32_t *
 int radhip_traversal_kernel_time(const radhip_traversal_t *t, double *out_ms,
                                  uint64_t *out_launches);
 uint64_t radhip_traversal_state_bytes(const radhip_traversal_t *t);
+/* traversals resident on the device at once (one wavefront each): batch sizes that are a
+ * multiple of it avoid a partially filled last round */
+int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t *out);
 
 /* per-traversal stop targets (each clamped to n_to_score): a traversal parks (status 3) once
  * n_scored >= its target and resumes when the target is raised — the hook the sharded
@@ -227,6 +230,10 @@ int radhip_comm_world(const radhip_comm_t *c);
  * (ascending score, ties by bytes of "{node_id}:{level}") */
 uint64_t radhip_rad_key(uint32_t and_cnt, uint32_t or_cnt, uint32_t slot, uint32_t level);
 void radhip_rad_key_decode(uint64_t key, uint32_t *slot, uint32_t *level);
+/* test hook: the same key evaluated by the device code path (float-reciprocal q, comparison-tree
+ * digit count) for n (and, or, slot, level) tuples */
+int radhip_debug_device_keys(radhip_index_t *idx, const uint32_t *and_cnt, const uint32_t *or_cnt,
+                             const uint32_t *slot, const uint32_t *level, uint64_t n, uint64_t *out_keys);
 
 #ifdef __cplusplus
 }

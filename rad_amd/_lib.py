@@ -74,6 +74,7 @@ SIGNATURES = {
     "radhip_traversal_results": (C.c_int, [_P, _U32, _P, _P, _P, _U64, C.POINTER(_U64)]),
     "radhip_traversal_pop_log": (C.c_int, [_P, _U32, _P, _P, _U64, C.POINTER(_U64)]),
     "radhip_traversal_kernel_time": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_U64)]),
+    "radhip_traversal_resident_capacity": (C.c_int, [_P, C.POINTER(_U32)]),
     "radhip_traversal_state_bytes": (_U64, [_P]),
     "radhip_traversal_set_targets": (C.c_int, [_P, _P]),
     "radhip_traversal_frontier": (C.c_int, [_P, _P, _P]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "radhip_comm_rank": (C.c_int, [_P]),
     "radhip_comm_world": (C.c_int, [_P]),
     "radhip_rad_key": (_U64, [_U32, _U32, _U32, _U32]),
+    "radhip_debug_device_keys": (C.c_int, [_P, _P, _P, _P, _P, _U64, _P]),
     "radhip_rad_key_decode": (None, [_U64, C.POINTER(_U32), C.POINTER(_U32)]),
 }
 

@@ -166,6 +166,32 @@ __host__ __device__ __forceinline__ uint64_t rh_make_key(uint32_t q24, uint32_t 
     uint32_t p = (slot + 1u) * rh_pow10(dl) - 1u;
     return ((uint64_t)q24 << 38) | ((uint64_t)p << 8) | ((uint64_t)dl << 4) | (uint64_t)rh_level_rank(level);
 }
+// ---- device-tuned restatements (same values; tests/test_gpu_kernels.py::test_device_keys) ----
+// floor((o-a) * 2^23 / o) without double precision: float reciprocal estimate (within +-2),
+// then an exact remainder fix-up in wrap-around 32-bit arithmetic (the true remainder is small).
+__device__ __forceinline__ uint32_t rh_q24_dev(uint32_t a, uint32_t o) {
+    const uint32_t x = o - a;
+    uint32_t q = (uint32_t)((float)x * __frcp_rn((float)o) * 8388608.0f);
+    int32_t r = (int32_t)((x << 23) - q * o);
+    if (r < 0) { q -= 1u; r += (int32_t)o; }
+    if (r < 0) { q -= 1u; r += (int32_t)o; }
+    if (r >= (int32_t)o) { q += 1u; r -= (int32_t)o; }
+    if (r >= (int32_t)o) { q += 1u; r -= (int32_t)o; }
+    return o == 0u ? 0u : q;
+}
+// digit count and 10^(9-d) by a comparison tree instead of nine compares + a select chain
+__device__ __forceinline__ uint64_t rh_make_key_dev(uint32_t q24, uint32_t slot, uint32_t level) {
+    uint32_t dl, m;
+    if (slot < 10000u) {
+        if (slot < 100u) { const bool c = slot < 10u; dl = c ? 8u : 7u; m = c ? 100000000u : 10000000u; }
+        else { const bool c = slot < 1000u; dl = c ? 6u : 5u; m = c ? 1000000u : 100000u; }
+    } else if (slot < 100000000u) {
+        if (slot < 1000000u) { const bool c = slot < 100000u; dl = c ? 4u : 3u; m = c ? 10000u : 1000u; }
+        else { const bool c = slot < 10000000u; dl = c ? 2u : 1u; m = c ? 100u : 10u; }
+    } else { dl = 0u; m = 1u; }
+    const uint32_t p = (slot + 1u) * m - 1u;
+    return ((uint64_t)q24 << 38) | ((uint64_t)p << 8) | ((uint64_t)dl << 4) | (uint64_t)rh_level_rank(level);
+}
 __host__ __device__ __forceinline__ void rh_decode_key(uint64_t key, uint32_t *slot, uint32_t *level) {
     uint32_t p = (uint32_t)(key >> 8) & 0x3FFFFFFFu;
     uint32_t dl = (uint32_t)(key >> 4) & 0xFu;

@@ -73,6 +73,7 @@ struct TravParams {
     uint32_t n_top, cap0, capU, nq;
     int32_t start_level;
     uint32_t spread_shift;   // new keys of an expansion go to lanes (i << spread_shift) + rot
+    uint32_t spec_passes;    // 1 or 2: speculative row gathers cover every neighbour; 0: disabled
     uint64_t n_to_score, max_pops;
     TravHeader *hdr;
     const uint4 *queries;
@@ -106,7 +107,7 @@ struct TravLds {
     uint32_t new_h[64];
     uint32_t new_and[64];
     uint32_t new_or[64];
-    uint32_t claim[256];
+    uint32_t claim[128];
 };
 
 // ascending in-place bitonic sort of s[0..P), P a power of two, by one wave
@@ -154,7 +155,7 @@ __device__ __forceinline__ uint32_t key_slot(unsigned long long key) {
 }
 
 template <int LPR>
-__global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
+__global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
     __shared__ TravLds L;
     const uint32_t lane = threadIdx.x;
     const uint32_t q = blockIdx.x;
@@ -352,9 +353,9 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
                 }
                 if (!__ballot(cand)) break;
                 const uint32_t tag = (h << 6) | lane;
-                if (cand) L.claim[h & 255u] = tag;
+                if (cand) L.claim[h & 127u] = tag;
                 WSYNC();
-                const uint32_t got = cand ? L.claim[h & 255u] : 0u;
+                const uint32_t got = cand ? L.claim[h & 127u] : 0u;
                 WSYNC();
                 if (cand) {
                     if (got == tag) { isnew = true; cand = false; }                    // bucket is mine
@@ -401,16 +402,121 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
                 __hip_atomic_store(&ht[L.new_h[ni]], (unsigned long long)s2 | ((unsigned long long)(a | (o << 12) | (level == 0 ? VAL_V0 : 0u)) << 32),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 scored[n_scored + ni] = make_uint2(s2, a | (o << 16));
-                key = rh_make_key(rh_q24(a, o), s2, level);
+                key = rh_make_key_dev(rh_q24_dev(a, o), s2, level);
             }
             n_scored += nn;
             enqueue(mine, key);
         }
         if (__ballot(push_old)) {
             unsigned long long key = RH_KEY_INF;
-            if (push_old) key = rh_make_key(rh_q24(val & 0xFFFu, (val >> 12) & 0xFFFu), slot, level);
+            if (push_old) key = rh_make_key_dev(rh_q24_dev(val & 0xFFFu, (val >> 12) & 0xFFFu), slot, level);
             enqueue(push_old, key);
         }
+    };
+
+    // ---- same as process() for one adjacency row, with the fingerprint rows of ALL neighbours
+    // gathered speculatively while the hash probes are in flight: one dependent HBM round trip
+    // less per expansion, paid with the rows of already-scored neighbours.
+    auto process_spec = [&](uint32_t slot, bool valid, uint32_t level, uint32_t rot) {
+        constexpr uint32_t RPP = 64 / LPR;
+        L.new_slot[lane] = valid ? slot : RADHIP_NO_SLOT;
+        WSYNC();
+        const uint32_t r0 = lane / LPR, r1 = (RPP + lane / LPR) & 63u;
+        const uint32_t s0 = L.new_slot[r0];
+        const uint32_t s1 = P.spec_passes > 1u ? L.new_slot[r1] : RADHIP_NO_SLOT;
+        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+        if (s0 != RADHIP_NO_SLOT) v0 = P.fp[(uint64_t)s0 * LPR + chunk];
+        if (s1 != RADHIP_NO_SLOT) v1 = P.fp[(uint64_t)s1 * LPR + chunk];
+        bool go = valid;
+        if (level > 0) {
+            if (go) {
+                const unsigned long long kk = (((unsigned long long)slot << 4) | level) + 1ull;
+                uint32_t hu = (uint32_t)((kk * 0x9E3779B97F4A7C15ull) >> ut_shift);
+                bool fresh = false;
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&ut[hu], 0ull, kk);
+                    if (old == 0ull) { fresh = true; break; }
+                    if (old == kk) break;
+                    hu = (hu + 1u) & ut_mask;
+                }
+                go = fresh;
+            }
+            n_upper += (uint64_t)__popcll(__ballot(go));
+            if (n_upper > ut_limit) { status = RADHIP_E_CAPACITY; return; }
+        }
+        bool isnew = false;
+        uint32_t h = 0, val = 0;
+        {
+            bool pending = go, cand = false;
+            if (go) h = (slot * 2654435769u) >> ht_shift;
+            for (;;) {
+                if (pending) {
+                    for (;;) {
+                        const unsigned long long e = ld64(&ht[h]);
+                        if (e == HT_EMPTY64) { cand = true; break; }
+                        if ((uint32_t)e == slot) { val = (uint32_t)(e >> 32); break; }
+                        h = (h + 1u) & ht_mask;
+                    }
+                    pending = false;
+                }
+                if (!__ballot(cand)) break;
+                const uint32_t tag = (h << 6) | lane;
+                if (cand) L.claim[h & 127u] = tag;
+                WSYNC();
+                const uint32_t got = cand ? L.claim[h & 127u] : 0u;
+                WSYNC();
+                if (cand) {
+                    if (got == tag) { isnew = true; cand = false; }
+                    else if ((got >> 6) == h) { cand = false; pending = true; h = (h + 1u) & ht_mask; }
+                }
+            }
+        }
+        bool push_old = false;
+        if (go && !isnew) {
+            if (level == 0) {
+                if (!(val & VAL_V0)) {
+                    st_relaxed(reinterpret_cast<uint32_t *>(&ht[h]) + 1, val | VAL_V0);
+                    push_old = true;
+                }
+            } else push_old = true;
+        }
+        // counts of every gathered row
+        {
+            const uint32_t rp0 = rh_group_sum<LPR>(rh_popc4(v0)), aa0 = rh_group_sum<LPR>(rh_popc4_and(v0, qv));
+            if (chunk == 0) { L.new_and[r0] = aa0; L.new_or[r0] = qpop + rp0 - aa0; }
+            if (P.spec_passes > 1u) {
+                const uint32_t rp1 = rh_group_sum<LPR>(rh_popc4(v1)), aa1 = rh_group_sum<LPR>(rh_popc4_and(v1, qv));
+                if (chunk == 0) { L.new_and[r1] = aa1; L.new_or[r1] = qpop + rp1 - aa1; }
+            }
+        }
+        const unsigned long long nb = __ballot(isnew);
+        const uint32_t nn = (uint32_t)__popcll(nb);
+        L.new_h[lane] = h;
+        L.claim[lane] = isnew ? (uint32_t)__popcll(nb & lt_mask) : 0xFFFFFFFFu;
+        WSYNC();
+        if (nn) {
+            const uint32_t sh = P.spread_shift;
+            const uint32_t u = (lane - rot) & 63u;
+            const uint32_t j = u >> sh;
+            const uint32_t rk = ((u & ((1u << sh) - 1u)) == 0u) ? L.claim[j] : 0xFFFFFFFFu;
+            const bool mine = rk != 0xFFFFFFFFu;
+            unsigned long long key = RH_KEY_INF;
+            if (mine) {
+                const uint32_t s2 = L.new_slot[j], a = L.new_and[j], o = L.new_or[j];
+                __hip_atomic_store(&ht[L.new_h[j]], (unsigned long long)s2 | ((unsigned long long)(a | (o << 12) | (level == 0 ? VAL_V0 : 0u)) << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                scored[n_scored + rk] = make_uint2(s2, a | (o << 16));
+                key = rh_make_key_dev(rh_q24_dev(a, o), s2, level);
+            }
+            n_scored += nn;
+            enqueue(mine, key);
+        }
+        if (__ballot(push_old)) {
+            unsigned long long key = RH_KEY_INF;
+            if (push_old) key = rh_make_key_dev(rh_q24_dev(val & 0xFFFu, (val >> 12) & 0xFFFu), slot, level);
+            enqueue(push_old, key);
+        }
+        WSYNC();
     };
 
     // ---- prime ---------------------------------------------------------------
@@ -463,7 +569,8 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
         }
         const bool valid = nbr != RADHIP_NO_SLOT;
         n_nbr += (uint64_t)__popcll(__ballot(valid));
-        process(nbr, valid, level, false, (uint32_t)(n_pops * 7u) & 63u);
+        if (P.spec_passes) process_spec(nbr, valid, level, (uint32_t)(n_pops * 7u) & 63u);
+        else process(nbr, valid, level, false, (uint32_t)(n_pops * 7u) & 63u);
         if (status) break;
         // descend: same node, one level down, same score
         if (level > 0) {
@@ -497,7 +604,7 @@ __global__ __launch_bounds__(64) void trav_kernel(TravParams P) {
             const bool any0 = __ballot(push0) != 0;
             if (any0) {
                 if (nl > 0) n_upper++;
-                enqueue(push0, rh_make_key((uint32_t)(mk >> 38), node, nl));
+                enqueue(push0, rh_make_key_dev((uint32_t)(mk >> 38), node, nl));
             }
         }
     }
@@ -625,6 +732,9 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
         while (p2 < w) { p2 <<= 1; }
         while ((p2 << sh) > 64u && sh > 0) sh--;
         P.spread_shift = sh;
+        const uint32_t rpp = 64u / idx->lpr;
+        const uint32_t passes = (p2 + rpp - 1u) / rpp;   // p2 = pow2ceil(widest row) = lanes the spread covers
+        P.spec_passes = passes <= 2u ? passes : 0u;
     }
     P.ht_log2 = ht_log2; P.ut_log2 = ut_log2; P.scored_cap = scored_cap; P.pq_cap = pq_cap;
     t->hdr_bytes = (size_t)nq * sizeof(TravHeader);
@@ -802,5 +912,64 @@ extern "C" int radhip_traversal_frontier(const radhip_traversal_t *t, uint64_t *
         if (out_keys) out_keys[i] = hdr[i].frontier_key;
         if (out_scored) out_scored[i] = hdr[i].n_scored;
     }
+    return RADHIP_OK;
+}
+
+// ---- test hook: the device restatements of the queue key, evaluated on the GPU -------------
+__global__ void debug_keys_kernel(const uint32_t *a, const uint32_t *o, const uint32_t *slot, const uint32_t *level,
+                                  uint64_t n, unsigned long long *out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = rh_make_key_dev(rh_q24_dev(a[i], o[i]), slot[i], level[i]);
+}
+
+extern "C" int radhip_debug_device_keys(radhip_index_t *idx, const uint32_t *a, const uint32_t *o, const uint32_t *slot,
+                                        const uint32_t *level, uint64_t n, uint64_t *out_keys) {
+    if (!idx || !a || !o || !slot || !level || !out_keys) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (n == 0) return RADHIP_OK;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_TRY(rh_ensure_device(idx));
+    uint32_t *d[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned long long *dout = nullptr;
+    const uint32_t *src[4] = {a, o, slot, level};
+    int rc = RADHIP_OK;
+    for (int i = 0; i < 4 && rc == RADHIP_OK; ++i) {
+        if (hipMalloc((void **)&d[i], n * 4) != hipSuccess) rc = RADHIP_E_NOMEM;
+        else if (hipMemcpy(d[i], src[i], n * 4, hipMemcpyHostToDevice) != hipSuccess) rc = RADHIP_E_HIP;
+    }
+    if (rc == RADHIP_OK && hipMalloc((void **)&dout, n * 8) != hipSuccess) rc = RADHIP_E_NOMEM;
+    if (rc == RADHIP_OK) {
+        hipLaunchKernelGGL(debug_keys_kernel, dim3(1024), dim3(256), 0, idx->stream, d[0], d[1], d[2], d[3], n, dout);
+        if (hipStreamSynchronize(idx->stream) != hipSuccess) rc = RADHIP_E_HIP;
+        else if (hipMemcpy(out_keys, dout, n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = RADHIP_E_HIP;
+    }
+    for (int i = 0; i < 4; ++i) if (d[i]) (void)hipFree(d[i]);
+    if (dout) (void)hipFree(dout);
+    if (rc != RADHIP_OK) radhip_set_error("radhip_debug_device_keys failed (%d)", rc);
+    return rc;
+}
+
+// how many traversals are resident at once (waves the chip holds for this kernel): batches that
+// are a multiple of it avoid a partially filled last round
+extern "C" int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t *out) {
+    if (!idx || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_TRY(rh_ensure_device(idx));
+    int per_cu = 0;
+    hipError_t e;
+    switch (idx->lpr) {
+        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav_kernel<1>, 64, 0); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav_kernel<2>, 64, 0); break;
+        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav_kernel<4>, 64, 0); break;
+        case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav_kernel<8>, 64, 0); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav_kernel<16>, 64, 0); break;
+    }
+    RH_HIP(e);
+    hipDeviceProp_t prop;
+    RH_HIP(hipGetDeviceProperties(&prop, idx->device));
+    // The occupancy API over-reports by one wave per SIMD for SGPR-heavy kernels on gfx950 /
+    // ROCm 7.2 (MI355X_MICROARCH.md, "Residency"): trav_kernel uses > 96 SGPRs, which admits
+    // floor(800 / (112 + 16)) = 6 waves per SIMD = 24 single-wave workgroups per CU.
+    if (per_cu > 24) per_cu = 24;
+    *out = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
     return RADHIP_OK;
 }

@@ -106,6 +106,12 @@ class DeviceIndex:
         check(self._L.radhip_get_top_level_nodes(self._h, ptr(out), n.value, C.byref(n)))
         return out
 
+    def traversal_capacity(self) -> int:
+        """Traversals resident on the device at once (one wavefront each)."""
+        n = C.c_uint32(0)
+        check(self._L.radhip_traversal_resident_capacity(self._h, C.byref(n)))
+        return n.value
+
     # -- Tanimoto kernels ---------------------------------------------------
     def scan(self, queries: np.ndarray, first: int = 0, count: Optional[int] = None):
         """K1: (and, or) of every query against rows [first, first+count)."""

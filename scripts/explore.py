@@ -8,7 +8,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=100_000_000)
 ap.add_argument("--ndim", type=int, default=1024)
 ap.add_argument("--M", type=int, default=8)
-ap.add_argument("--nq", type=str, default="1024,4096")
+ap.add_argument("--nq", type=str, default="cap")
 ap.add_argument("--nts", type=str, default="100000")
 ap.add_argument("--mode", type=int, default=1)
 a = ap.parse_args()
@@ -22,7 +22,7 @@ inf = idx.info()
 print(f"n={a.n} synth rows {t1-t0:.2f}s graph {t2-t1:.2f}s max_level={inf.max_level} dev_bytes={inf.device_bytes/1e9:.2f} GB", flush=True)
 B = inf.row_stride
 for nts in [int(x) for x in a.nts.split(",")]:
-    for nq in [int(x) for x in a.nq.split(",")]:
+    for nq in [idx.traversal_capacity() * int(x[3:] or 1) if x.startswith("cap") else int(x) for x in a.nq.split(",")]:
         Q = idx.read_vectors(12345, nq)
         t3 = time.time()
         t = DeviceTraversal(idx, Q, nts)

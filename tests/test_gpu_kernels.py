@@ -159,3 +159,28 @@ def test_traversal_resume_in_rounds(gpu, oracle):
     for i in range(Q.shape[0]):
         for x, y in zip(t1.results(i), t2.results(Q.shape[0] - 1 - i)):
             assert np.array_equal(x, y)
+
+
+def test_device_keys_match_host_restatement(gpu):
+    """The device's float-reciprocal q and comparison-tree key (common.h *_dev) against the host
+    restatement that tests/test_key_order.py pins to the Redis order: every (and, or) with
+    or <= 2048, and slots around every power of ten."""
+    from rad_amd import _lib
+    from rad_amd._lib import check, ptr
+    L = _lib.lib()
+    idx = _mk_index(1024, 8)
+    ors = np.arange(0, 2049, dtype=np.uint32)
+    a = np.concatenate([np.arange(0, o + 1, dtype=np.uint32) for o in ors])
+    o = np.concatenate([np.full(o + 1, o, dtype=np.uint32) for o in ors])
+    rng = np.random.default_rng(0)
+    edge = np.array([0, 1, 9, 10, 11, 99, 100, 999, 1000, 9999, 10000, 99999, 100000, 999999, 1000000,
+                     9999999, 10000000, 99999999, 100000000, 999999999], np.uint32)
+    slot = np.concatenate([edge, rng.integers(0, 1_000_000_000, a.size - edge.size).astype(np.uint32)])
+    level = rng.integers(0, 16, a.size).astype(np.uint32)
+    out = np.empty(a.size, np.uint64)
+    check(L.radhip_debug_device_keys(idx._h, ptr(a), ptr(o), ptr(slot), ptr(level), a.size, ptr(out)))
+    q = np.where(o > 0, ((o.astype(np.int64) - a.astype(np.int64)) << 23) // np.maximum(o.astype(np.int64), 1), 0)
+    assert np.array_equal(out >> np.uint64(38), q.astype(np.uint64))
+    for i in np.concatenate([np.arange(edge.size), rng.integers(0, a.size, 5000)]):
+        assert int(out[i]) == L.radhip_rad_key(int(a[i]), int(o[i]), int(slot[i]), int(level[i]))
+    assert idx.traversal_capacity() >= 256 * 8

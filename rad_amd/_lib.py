@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "librad_hip.so")
+LIB_PATH = os.environ.get("RADHIP_LIB") or os.path.join(_HERE, "_build", "librad_hip.so")
 
 NO_SLOT = 0xFFFFFFFF
 TRAV_LOG_POPS = 1

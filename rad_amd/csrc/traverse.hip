@@ -92,6 +92,7 @@ struct TravParams {
     uint32_t *poplog_nodes;
     uint8_t *poplog_levels;
     uint64_t poplog_cap;
+    unsigned long long *prof;   // RH_PROFILE builds only: per-section cycle sums
 };
 
 __device__ __forceinline__ unsigned long long ld64(const unsigned long long *p) {
@@ -629,6 +630,8 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
     }
 }
 
+#include "traverse4.inc"
+
 // ================================================================== host side
 struct radhip_traversal {
     radhip_index *idx = nullptr;
@@ -639,6 +642,7 @@ struct radhip_traversal {
     uint4 *d_queries = nullptr;
     size_t ht_bytes = 0, ut_bytes = 0, scored_bytes = 0, pq_bytes = 0, stg_bytes = 0, runs_bytes = 0,
            rhead_bytes = 0, rsave_bytes = 0, hdr_bytes = 0, log_bytes = 0;
+    bool use4 = false;   // trav4_kernel (four traversals per wave) when every adjacency row is <= 16 wide
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0.0;
     uint64_t launches = 0;
@@ -711,6 +715,7 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     radhip_traversal *t = new (std::nothrow) radhip_traversal();
     if (!t) RH_FAIL(RADHIP_E_NOMEM, "out of host memory");
     t->idx = idx; t->nq = nq; t->n_to_score = n_to_score; t->flags = flags;
+    t->use4 = idx->cap0 <= 16 && idx->M <= 16 && getenv("RADHIP_NO_TRAV4") == nullptr;
     const uint64_t n_top = idx->n_top;
     if (n_to_score > idx->g_n) n_to_score = idx->g_n;  // cannot score more than exist
     t->n_to_score = n_to_score;
@@ -797,19 +802,49 @@ extern "C" int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, ui
     t->P.fp = idx->d_fp; t->P.adj0 = idx->d_adj0; t->P.upper_row = idx->d_upper_row;
     t->P.adjU = idx->d_adjU; t->P.top = idx->d_top;
     t->P.max_pops = max_pops;
+#ifdef RH_PROFILE
+    static unsigned long long *d_prof = nullptr;
+    if (!d_prof) { (void)hipMalloc((void **)&d_prof, 80); }
+    (void)hipMemset(d_prof, 0, 80);
+    t->P.prof = d_prof;
+#else
+    t->P.prof = nullptr;
+#endif
     RH_HIP(hipEventRecord(t->ev0, idx->stream));
-    switch (idx->lpr) {
-        case 1: hipLaunchKernelGGL(trav_kernel<1>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
-        case 2: hipLaunchKernelGGL(trav_kernel<2>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
-        case 4: hipLaunchKernelGGL(trav_kernel<4>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
-        case 8: hipLaunchKernelGGL(trav_kernel<8>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
-        default: hipLaunchKernelGGL(trav_kernel<16>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
+    if (t->use4) {
+        const uint32_t grid = (t->nq + 3u) / 4u;
+        switch (idx->lpr) {
+            case 1: hipLaunchKernelGGL(trav4_kernel<1>, dim3(grid), dim3(64), 0, idx->stream, t->P); break;
+            case 2: hipLaunchKernelGGL(trav4_kernel<2>, dim3(grid), dim3(64), 0, idx->stream, t->P); break;
+            case 4: hipLaunchKernelGGL(trav4_kernel<4>, dim3(grid), dim3(64), 0, idx->stream, t->P); break;
+            case 8: hipLaunchKernelGGL(trav4_kernel<8>, dim3(grid), dim3(64), 0, idx->stream, t->P); break;
+            default: hipLaunchKernelGGL(trav4_kernel<16>, dim3(grid), dim3(64), 0, idx->stream, t->P); break;
+        }
+    } else {
+        switch (idx->lpr) {
+            case 1: hipLaunchKernelGGL(trav_kernel<1>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
+            case 2: hipLaunchKernelGGL(trav_kernel<2>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
+            case 4: hipLaunchKernelGGL(trav_kernel<4>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
+            case 8: hipLaunchKernelGGL(trav_kernel<8>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
+            default: hipLaunchKernelGGL(trav_kernel<16>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
+        }
     }
     RH_HIP(hipGetLastError());
     RH_HIP(hipEventRecord(t->ev1, idx->stream));
     RH_HIP(hipStreamSynchronize(idx->stream));
     float ms = 0.f;
     RH_HIP(hipEventElapsedTime(&ms, t->ev0, t->ev1));
+#ifdef RH_PROFILE
+    {
+        unsigned long long hp[10];
+        (void)hipMemcpy(hp, t->P.prof, 80, hipMemcpyDeviceToHost);
+        unsigned long long tot = 0; for (int i = 0; i < 10; ++i) tot += hp[i];
+        const char *nm[10] = {"loophead", "flush", "pop+repivot", "decode+adj", "probe", "eval", "finish+enqueue", "old+descent-pre", "", ""};
+        fprintf(stderr, "[prof] total %llu cycles:", tot);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * hp[i] / (tot ? tot : 1));
+        fprintf(stderr, "\n");
+    }
+#endif
     t->kernel_ms += ms;
     t->launches++;
     std::vector<TravHeader> hdr(t->nq);
@@ -956,6 +991,16 @@ extern "C" int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t 
     RH_TRY(rh_ensure_device(idx));
     int per_cu = 0;
     hipError_t e;
+    const bool use4 = idx->cap0 <= 16 && idx->M <= 16 && getenv("RADHIP_NO_TRAV4") == nullptr;
+    if (use4) {
+        switch (idx->lpr) {
+            case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<1>, 64, 0); break;
+            case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<2>, 64, 0); break;
+            case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<4>, 64, 0); break;
+            case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<8>, 64, 0); break;
+            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<16>, 64, 0); break;
+        }
+    } else
     switch (idx->lpr) {
         case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav_kernel<1>, 64, 0); break;
         case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav_kernel<2>, 64, 0); break;
@@ -970,6 +1015,6 @@ extern "C" int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t 
     // ROCm 7.2 (MI355X_MICROARCH.md, "Residency"): trav_kernel uses > 96 SGPRs, which admits
     // floor(800 / (112 + 16)) = 6 waves per SIMD = 24 single-wave workgroups per CU.
     if (per_cu > 24) per_cu = 24;
-    *out = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+    *out = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount * (use4 ? 4u : 1u);
     return RADHIP_OK;
 }

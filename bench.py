@@ -3,8 +3,8 @@
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on; it fits
 one GPU): 100M x 1024-bit fingerprints resident in HBM, layered adjacency (connectivity 8,
-level-0 width 16), `nq` independent best-first RAD traversals (Tanimoto-scored) each run
-to n_to_score = 100k scored nodes.  One "step" = one pass of the hot path over one batch
+level-0 width 16), `nq` independent best-first RAD traversals (Tanimoto-scored; nq defaults to
+the number the device holds resident at once, 16384 on MI355X) each run to n_to_score = 100k.  One "step" = one pass of the hot path over one batch
 of nq synthetic queries: state re-arm (device memsets + query upload) + traversal kernel
 launch(es) to completion.  Corpus and graph are synthetic (closed-form generators on the
 device; no dataset or built index can be downloaded here) and are resident in HBM before
@@ -41,7 +41,8 @@ def parse_args():
     ap.add_argument("--n", type=int, default=100_000_000, help="rows per GPU")
     ap.add_argument("--ndim", type=int, default=1024)
     ap.add_argument("--connectivity", type=int, default=8)
-    ap.add_argument("--nq", type=int, default=4096, help="concurrent traversals per GPU per step")
+    ap.add_argument("--nq", type=int, default=0,
+                    help="concurrent traversals per GPU per step (0 = what the device holds resident at once)")
     ap.add_argument("--n-to-score", type=int, default=100_000)
     ap.add_argument("--corpus-mode", type=int, default=1, help="0 dense Bernoulli(0.5), 1 clustered sparse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,6 +96,8 @@ def main():
     idx.synth_graph(seed=777 + rank)
     info = idx.info()
     B = info.row_stride
+    if args.nq <= 0:
+        args.nq = idx.traversal_capacity()   # one wavefront row per traversal: fill the chip exactly once
 
     # query batches: rows of the logical corpus (identical on every rank), a different batch per step
     n_batches = args.warmup + args.steps
@@ -202,7 +205,7 @@ def main():
         "evals_per_s": evals_all / elapsed_max,
         "evals_per_expansion": evals_all / max(pops_all, 1.0),
         "roofline": {
-            "bound": "hbm", "kernel": "trav_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": "trav4_kernel" if (2 * M <= 16 and M <= 16) else "trav_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_launch_ms,
             "launches": k_launches,

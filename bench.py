@@ -209,6 +209,9 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_launch_ms,
             "launches": k_launches,
+            # real HBM bytes (PMC, measured offline: profiles/traffic_latest.json) over this run's launch time
+            "hbm_real_gbs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None,
+            "hbm_real_frac": (traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
         },
     }
 

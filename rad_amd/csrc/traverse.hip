@@ -34,7 +34,7 @@
 #define RH_S_CAP 512
 #endif
 #ifndef RH_MAX_RUNS
-#define RH_MAX_RUNS 2048
+#define RH_MAX_RUNS 8192
 #endif
 #define S_CAP ((uint32_t)RH_S_CAP)
 #define MAX_RUNS ((uint32_t)RH_MAX_RUNS)

@@ -184,3 +184,40 @@ def test_device_keys_match_host_restatement(gpu):
     for i in np.concatenate([np.arange(edge.size), rng.integers(0, a.size, 5000)]):
         assert int(out[i]) == L.radhip_rad_key(int(a[i]), int(o[i]), int(slot[i]), int(level[i]))
     assert idx.traversal_capacity() >= 256 * 8
+
+
+@pytest.mark.parametrize("kernel", ["trav4", "trav1"])
+def test_traversal_deep_queue_paths(gpu, oracle, kernel, monkeypatch):
+    """n_to_score large enough that the pivot queue flushes hundreds of sorted runs and re-pivots
+    hundreds of times (bench-scale code paths), for both traversal kernels, still bit-exact."""
+    from rad_amd.device import DeviceTraversal
+    if kernel == "trav1":
+        monkeypatch.setenv("RADHIP_NO_TRAV4", "1")
+    n, ndim, M, cap0, nts = 400_000, 1024, 8, 16, 60_000
+    idx = _mk_index(ndim, M, cap0)
+    idx.synth_vectors(n, seed=13, mode=1)
+    idx.synth_graph(seed=14)
+    X = oracle.synth_rows(0, n, n, ndim, 13, 1)
+    g = oracle.synth_graph(n, M, cap0, 14)
+    Q = X[[11, 70_001, 399_999, 5, 123_456]].copy()
+    t = DeviceTraversal(idx, Q, nts, log_pops=True)
+    assert t.run() == 0
+    st = t.stats()
+    assert st.n_flush.min() > 50 and st.n_repivot.min() > 50
+    for i in range(Q.shape[0]):
+        want = oracle.rad_traverse(g, X, Q[i], nts)
+        s, a, o = t.results(i)
+        nodes, levels = t.pop_log(i)
+        assert np.array_equal(nodes, want.pop_nodes) and np.array_equal(levels, want.pop_levels)
+        assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt)
+    t.close()
+    # the same in bounded rounds (state persisted / restored between launches)
+    t2 = DeviceTraversal(idx, Q[:2], nts)
+    rounds = 0
+    while t2.run(max_pops=1500) > 0:
+        rounds += 1
+        assert rounds < 1000
+    for i in range(2):
+        want = oracle.rad_traverse(g, X, Q[i], nts, log_pops=False)
+        s, a, o = t2.results(i)
+        assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt)

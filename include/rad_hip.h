@@ -133,6 +133,8 @@ int radhip_tanimoto_scan(radhip_index_t *idx, const uint8_t *queries, uint32_t n
 int radhip_tanimoto_gather(radhip_index_t *idx, const uint8_t *queries, uint32_t nq,
                            const uint32_t *cand_slots, const uint64_t *cand_offsets,
                            uint32_t *and_out, uint32_t *or_out);
+/* device time (HIP events, this thread's last radhip_tanimoto_scan / _gather call), kernels only */
+double radhip_last_kernel_ms(void);
 /* float edge value: 1.0f - (float)and/(float)or, 0.0f when or == 0 */
 float radhip_distance_f32(uint32_t and_cnt, uint32_t or_cnt);
 

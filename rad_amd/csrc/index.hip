@@ -521,6 +521,9 @@ extern "C" int radhip_get_top_level_nodes(const radhip_index_t *cidx, uint32_t *
     return RADHIP_OK;
 }
 
+static thread_local double g_last_kernel_ms = 0.0;
+extern "C" double radhip_last_kernel_ms(void) { return g_last_kernel_ms; }
+
 // ------------------------------------------------------- K1: corpus scan --
 // One wave-load covers 64/LPR rows (1 KiB contiguous for 1024-bit rows): lane
 // l reads the 16-B chunk (l % LPR) of row (l / LPR).  NQ query chunks stay in
@@ -618,8 +621,13 @@ extern "C" int radhip_tanimoto_scan(radhip_index_t *idx, const uint8_t *queries,
     RH_G(hipMalloc((void **)&dorr, (size_t)pass * count * 4));
     RH_G(hipMemcpyAsync(dq, padded.data(), padded.size(), hipMemcpyHostToDevice, idx->stream));
     RH_G(hipMemcpyAsync(dpop, pop.data(), (size_t)nq * 4, hipMemcpyHostToDevice, idx->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    g_last_kernel_ms = 0.0;
     for (uint32_t q0 = 0; q0 < nq && rc == RADHIP_OK; q0 += pass) {
         const int k = (int)std::min<uint32_t>(pass, nq - q0);
+        (void)hipEventRecord(e0, idx->stream);
         const uint4 *dqk = dq + (size_t)q0 * idx->lpr;
         switch (idx->lpr) {
             case 1: rc = launch_scan<1>(idx, k, first, count, dqk, dpop + q0, da, dorr); break;
@@ -629,10 +637,15 @@ extern "C" int radhip_tanimoto_scan(radhip_index_t *idx, const uint8_t *queries,
             default: rc = launch_scan<16>(idx, k, first, count, dqk, dpop + q0, da, dorr); break;
         }
         if (rc != RADHIP_OK) break;
+        (void)hipEventRecord(e1, idx->stream);
         RH_G(hipMemcpyAsync(and_out + (size_t)q0 * count, da, (size_t)k * count * 4, hipMemcpyDeviceToHost, idx->stream));
         RH_G(hipMemcpyAsync(or_out + (size_t)q0 * count, dorr, (size_t)k * count * 4, hipMemcpyDeviceToHost, idx->stream));
         RH_G(hipStreamSynchronize(idx->stream));
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) g_last_kernel_ms += ms;
     }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     cleanup();
     return rc;
 }
@@ -708,6 +721,10 @@ extern "C" int radhip_tanimoto_gather(radhip_index_t *idx, const uint8_t *querie
     RH_G(hipMemcpyAsync(dps, cand_slots, n_pairs * 4, hipMemcpyHostToDevice, idx->stream));
     const uint64_t ppb = 256 / idx->lpr;
     uint32_t grid = (uint32_t)std::min<uint64_t>((n_pairs + ppb - 1) / ppb, 256ull * 16ull);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, idx->stream);
     switch (idx->lpr) {
         case 1: hipLaunchKernelGGL(gather_kernel<1>, dim3(grid), dim3(256), 0, idx->stream, idx->d_fp, dq, dpop, dpq, dps, n_pairs, da, dorr); break;
         case 2: hipLaunchKernelGGL(gather_kernel<2>, dim3(grid), dim3(256), 0, idx->stream, idx->d_fp, dq, dpop, dpq, dps, n_pairs, da, dorr); break;
@@ -715,10 +732,17 @@ extern "C" int radhip_tanimoto_gather(radhip_index_t *idx, const uint8_t *querie
         case 8: hipLaunchKernelGGL(gather_kernel<8>, dim3(grid), dim3(256), 0, idx->stream, idx->d_fp, dq, dpop, dpq, dps, n_pairs, da, dorr); break;
         default: hipLaunchKernelGGL(gather_kernel<16>, dim3(grid), dim3(256), 0, idx->stream, idx->d_fp, dq, dpop, dpq, dps, n_pairs, da, dorr); break;
     }
+    (void)hipEventRecord(e1, idx->stream);
     RH_G(hipGetLastError());
     RH_G(hipMemcpyAsync(and_out, da, n_pairs * 4, hipMemcpyDeviceToHost, idx->stream));
     RH_G(hipMemcpyAsync(or_out, dorr, n_pairs * 4, hipMemcpyDeviceToHost, idx->stream));
     RH_G(hipStreamSynchronize(idx->stream));
+    {
+        float ms = 0.f;
+        g_last_kernel_ms = hipEventElapsedTime(&ms, e0, e1) == hipSuccess ? ms : 0.0;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
     cleanup();
     return RADHIP_OK;
 #undef RH_G

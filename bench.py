@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=100_000_000, help="rows per GPU")
+    ap.add_argument("--rows", dest="n", type=int, default=100_000_000, help="rows per GPU")
     ap.add_argument("--ndim", type=int, default=1024)
     ap.add_argument("--connectivity", type=int, default=8)
     ap.add_argument("--nq", type=int, default=0,
@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--corpus-mode", type=int, default=1, help="0 dense Bernoulli(0.5), 1 clustered sparse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-traversals", type=int, default=0, help="0 = 32 per host core")
+    ap.add_argument("--exchange", choices=["rccl", "gloo"], default="rccl",
+                    help="N>1 exchange step: rccl (product path) or gloo (rehearsal of the N>1 logic on a box with one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     return ap.parse_args()
 
 
@@ -55,6 +58,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_device:
+        local_rank = 0
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -77,10 +82,20 @@ def main():
         raise SystemExit("bench.py needs an MI355X per rank; there is no CPU fallback")
 
     comm = None
-    if dist is not None:
+    allgather = None
+    if dist is not None and args.exchange == "rccl":
         box = [RcclComm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         comm = RcclComm(rank, world, box[0], local_rank)
+        allgather = comm.allgather_u64
+    elif dist is not None:
+        import torch
+
+        def allgather(a):
+            t = torch.from_numpy(np.ascontiguousarray(a, np.uint64).view(np.int64))
+            outs = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(outs, t)
+            return np.stack([o.numpy().view(np.uint64) for o in outs])
 
     def barrier_sync():
         if dist is not None:
@@ -114,11 +129,11 @@ def main():
 
     def step(b):
         trav.reset(batches[b])
-        if comm is None:
+        if allgather is None:
             running = trav.run(0)
             assert running == 0
         else:
-            st_ = ShardedTraversal(trav, comm.allgather_u64, rank, world, args.n_to_score * world, local_cap)
+            st_ = ShardedTraversal(trav, allgather, rank, world, args.n_to_score * world, local_cap)
             st_.run()
             exch["rounds"] += st_.rounds
             exch["bytes"] += st_.exchanged_bytes

@@ -42,6 +42,11 @@
 #define HT_EMPTY64 0xFFFFFFFFFFFFFFFFull
 #define VAL_V0 (1u << 24)
 #define VAL_PENDING 0xFFFFFFFEu
+// Lazy clearing: bits 31..25 of an entry's value word carry the epoch of the batch that wrote it
+// (0x7F, what the 0xFF memset leaves, is never a live epoch); entries of older epochs read as empty,
+// so re-arming the state for a new batch of queries does not touch the tables (49 GB at bench size).
+#define VAL_EPOCH_SHIFT 25
+#define EPOCH_LIMIT 127u
 #define DQ_INIT (1u << 14)
 #define DQ_MAX (1u << 23)
 
@@ -72,6 +77,7 @@ struct TravParams {
     const uint32_t *adj0, *upper_row, *adjU, *top;
     uint32_t n_top, cap0, capU, nq;
     int32_t start_level;
+    uint32_t epoch;          // current batch (see VAL_EPOCH_SHIFT)
     uint32_t spread_shift;   // new keys of an expansion go to lanes (i << spread_shift) + rot
     uint32_t spec_passes;    // 1 or 2: speculative row gathers cover every neighbour; 0: disabled
     uint64_t n_to_score, max_pops;
@@ -97,6 +103,23 @@ struct TravParams {
 
 __device__ __forceinline__ unsigned long long ld64(const unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool ht_is_empty(unsigned long long e, uint32_t epoch) { return (uint32_t)(e >> 57) != epoch; }
+// test-and-set of (slot<<4|level) in the upper-level visited set; entries of older epochs are free
+__device__ __forceinline__ bool ut_test_and_set(unsigned long long *ut, uint32_t mask, uint32_t shift,
+                                                unsigned long long body, uint32_t epoch) {
+    const unsigned long long kk = (((unsigned long long)epoch << 40) | body) + 1ull;
+    uint32_t h = (uint32_t)(((body + 1ull) * 0x9E3779B97F4A7C15ull) >> shift);
+    for (;;) {
+        const unsigned long long old = atomicCAS(&ut[h], 0ull, kk);
+        if (old == 0ull) return true;
+        if (old == kk) return false;
+        if (((old - 1ull) >> 40) != (unsigned long long)epoch) {   // stale: take it over
+            if (atomicCAS(&ut[h], old, kk) == old) return true;
+            continue;                                              // another lane got there first: look again
+        }
+        h = (h + 1u) & mask;
+    }
 }
 __device__ __forceinline__ void st_relaxed(uint32_t *p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -319,16 +342,8 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
         bool go = valid;
         if (level > 0) {
             if (go) {
-                const unsigned long long kk = (((unsigned long long)slot << 4) | level) + 1ull;
-                uint32_t h = (uint32_t)((kk * 0x9E3779B97F4A7C15ull) >> ut_shift);
-                bool fresh = false;
-                for (;;) {
-                    const unsigned long long old = atomicCAS(&ut[h], 0ull, kk);
-                    if (old == 0ull) { fresh = true; break; }
-                    if (old == kk) break;
-                    h = (h + 1u) & ut_mask;
-                }
-                go = fresh || prime;
+                const bool fresh_u = ut_test_and_set(ut, ut_mask, ut_shift, ((unsigned long long)slot << 4) | level, P.epoch);
+                go = fresh_u || prime;
             }
             n_upper += (uint64_t)__popcll(__ballot(go));
             if (n_upper > ut_limit) { status = RADHIP_E_CAPACITY; return; }
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
                 if (pending) {
                     for (;;) {
                         const unsigned long long e = ld64(&ht[h]);
-                        if (e == HT_EMPTY64) { cand = true; break; }
+                        if (ht_is_empty(e, P.epoch)) { cand = true; break; }
                         if ((uint32_t)e == slot) { val = (uint32_t)(e >> 32); break; }
                         h = (h + 1u) & ht_mask;
                     }
@@ -400,7 +415,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
             unsigned long long key = RH_KEY_INF;
             if (mine) {
                 const uint32_t s2 = L.new_slot[ni], a = L.new_and[ni], o = L.new_or[ni];
-                __hip_atomic_store(&ht[L.new_h[ni]], (unsigned long long)s2 | ((unsigned long long)(a | (o << 12) | (level == 0 ? VAL_V0 : 0u)) << 32),
+                __hip_atomic_store(&ht[L.new_h[ni]], (unsigned long long)s2 | ((unsigned long long)(a | (o << 12) | (level == 0 ? VAL_V0 : 0u) | (P.epoch << VAL_EPOCH_SHIFT)) << 32),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 scored[n_scored + ni] = make_uint2(s2, a | (o << 16));
                 key = rh_make_key_dev(rh_q24_dev(a, o), s2, level);
@@ -431,16 +446,8 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
         bool go = valid;
         if (level > 0) {
             if (go) {
-                const unsigned long long kk = (((unsigned long long)slot << 4) | level) + 1ull;
-                uint32_t hu = (uint32_t)((kk * 0x9E3779B97F4A7C15ull) >> ut_shift);
-                bool fresh = false;
-                for (;;) {
-                    const unsigned long long old = atomicCAS(&ut[hu], 0ull, kk);
-                    if (old == 0ull) { fresh = true; break; }
-                    if (old == kk) break;
-                    hu = (hu + 1u) & ut_mask;
-                }
-                go = fresh;
+                const bool fresh_u = ut_test_and_set(ut, ut_mask, ut_shift, ((unsigned long long)slot << 4) | level, P.epoch);
+                go = fresh_u;
             }
             n_upper += (uint64_t)__popcll(__ballot(go));
             if (n_upper > ut_limit) { status = RADHIP_E_CAPACITY; return; }
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
                 if (pending) {
                     for (;;) {
                         const unsigned long long e = ld64(&ht[h]);
-                        if (e == HT_EMPTY64) { cand = true; break; }
+                        if (ht_is_empty(e, P.epoch)) { cand = true; break; }
                         if ((uint32_t)e == slot) { val = (uint32_t)(e >> 32); break; }
                         h = (h + 1u) & ht_mask;
                     }
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
             unsigned long long key = RH_KEY_INF;
             if (mine) {
                 const uint32_t s2 = L.new_slot[j], a = L.new_and[j], o = L.new_or[j];
-                __hip_atomic_store(&ht[L.new_h[j]], (unsigned long long)s2 | ((unsigned long long)(a | (o << 12) | (level == 0 ? VAL_V0 : 0u)) << 32),
+                __hip_atomic_store(&ht[L.new_h[j]], (unsigned long long)s2 | ((unsigned long long)(a | (o << 12) | (level == 0 ? VAL_V0 : 0u) | (P.epoch << VAL_EPOCH_SHIFT)) << 32),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 scored[n_scored + rk] = make_uint2(s2, a | (o << 16));
                 key = rh_make_key_dev(rh_q24_dev(a, o), s2, level);
@@ -579,24 +586,17 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
             bool push0 = false;
             if (lane == 0) {
                 if (nl > 0) {
-                    const unsigned long long kk = (((unsigned long long)node << 4) | nl) + 1ull;
-                    uint32_t h = (uint32_t)((kk * 0x9E3779B97F4A7C15ull) >> ut_shift);
-                    for (;;) {
-                        const unsigned long long old = atomicCAS(&ut[h], 0ull, kk);
-                        if (old == 0ull) { push0 = true; break; }
-                        if (old == kk) break;
-                        h = (h + 1u) & ut_mask;
-                    }
+                    push0 = ut_test_and_set(ut, ut_mask, ut_shift, ((unsigned long long)node << 4) | nl, P.epoch);
                 } else {
                     uint32_t h = (node * 2654435769u) >> ht_shift;
                     unsigned long long e;
                     for (;;) {  // node is scored, hence present
                         e = __hip_atomic_load(&ht[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((uint32_t)e == node || e == HT_EMPTY64) break;  // EMPTY unreachable by construction
+                        if (ht_is_empty(e, P.epoch) || (uint32_t)e == node) break;  // empty unreachable by construction
                         h = (h + 1u) & ht_mask;
                     }
                     const uint32_t val = (uint32_t)(e >> 32);
-                    if ((uint32_t)e == node && !(val & VAL_V0)) {
+                    if (!ht_is_empty(e, P.epoch) && (uint32_t)e == node && !(val & VAL_V0)) {
                         st_relaxed(reinterpret_cast<uint32_t *>(&ht[h]) + 1, val | VAL_V0);
                         push0 = true;
                     }
@@ -642,6 +642,7 @@ struct radhip_traversal {
     uint4 *d_queries = nullptr;
     size_t ht_bytes = 0, ut_bytes = 0, scored_bytes = 0, pq_bytes = 0, stg_bytes = 0, runs_bytes = 0,
            rhead_bytes = 0, rsave_bytes = 0, hdr_bytes = 0, log_bytes = 0;
+    bool fresh_tables = true;   // tables not cleared yet (first upload)
     bool use4 = false;   // trav4_kernel (four traversals per wave) when every adjacency row is <= 16 wide
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0.0;
@@ -672,8 +673,16 @@ static int trav_upload_queries(radhip_traversal *t, const uint8_t *queries) {
     }
     RH_HIP(hipMemcpyAsync(t->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, idx->stream));
     RH_HIP(hipMemcpyAsync(t->P.hdr, hdr.data(), t->hdr_bytes, hipMemcpyHostToDevice, idx->stream));
-    RH_HIP(hipMemsetAsync(t->P.ht, 0xFF, t->ht_bytes, idx->stream));
-    RH_HIP(hipMemsetAsync(t->P.ut, 0x00, t->ut_bytes, idx->stream));
+    if (t->fresh_tables) {
+        t->P.epoch = 0;
+        t->fresh_tables = false;
+        RH_HIP(hipMemsetAsync(t->P.ht, 0xFF, t->ht_bytes, idx->stream));
+        RH_HIP(hipMemsetAsync(t->P.ut, 0x00, t->ut_bytes, idx->stream));
+    } else if (++t->P.epoch >= EPOCH_LIMIT) {   // epoch space exhausted: really clear
+        t->P.epoch = 0;
+        RH_HIP(hipMemsetAsync(t->P.ht, 0xFF, t->ht_bytes, idx->stream));
+        RH_HIP(hipMemsetAsync(t->P.ut, 0x00, t->ut_bytes, idx->stream));
+    }
     RH_HIP(hipStreamSynchronize(idx->stream));
     t->kernel_ms = 0.0;
     t->launches = 0;

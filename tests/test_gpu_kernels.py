@@ -221,3 +221,29 @@ def test_traversal_deep_queue_paths(gpu, oracle, kernel, monkeypatch):
         want = oracle.rad_traverse(g, X, Q[i], nts, log_pops=False)
         s, a, o = t2.results(i)
         assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt)
+
+
+def test_reset_reuses_tables_across_epochs(gpu, oracle):
+    """reset() re-arms the state without clearing the visited tables (epoch tags): many batches in a
+    row — past the epoch wrap-around — must each match the oracle, on levels 0 and above."""
+    from rad_amd.device import DeviceTraversal
+    n = 6000
+    X = oracle.synth_rows(0, n, n, 1024, 31, 1)
+    g = oracle.synth_graph(n, 8, 16, 32)
+    idx = _mk_index(1024, 8, 16)
+    idx.load_vectors(X)
+    idx.load_graph(g.levels, g.adj0, g.upper_row, g.adjU, g.max_level, g.entry)
+    rng = np.random.default_rng(5)
+    t = DeviceTraversal(idx, X[:6], 400)
+    for batch in range(140):                       # EPOCH_LIMIT is 127
+        Q = X[rng.integers(0, n, 6)].copy()
+        if batch:
+            t.reset(Q)
+        else:
+            t.reset(Q)
+        assert t.run() == 0
+        if batch % 9 == 0 or batch > 120:
+            for i in (0, 5):
+                want = oracle.rad_traverse(g, X, Q[i], 400, log_pops=False)
+                s, a, o = t.results(i)
+                assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt), (batch, i)

@@ -41,7 +41,6 @@
 #define RK 4
 #define HT_EMPTY64 0xFFFFFFFFFFFFFFFFull
 #define VAL_V0 (1u << 24)
-#define VAL_PENDING 0xFFFFFFFEu
 // Lazy clearing: bits 31..25 of an entry's value word carry the epoch of the batch that wrote it
 // (0x7F, what the 0xFF memset leaves, is never a live epoch); entries of older epochs read as empty,
 // so re-arming the state for a new batch of queries does not touch the tables (49 GB at bench size).

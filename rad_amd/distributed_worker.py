@@ -55,7 +55,7 @@ class DistributedWorker:
         if self.is_running:
             return False
         if self.coordination_service is None or self.scoring_fn is None:
-            logger.error("worker %s needs a coordination service and a scoring function", self.worker_id)
+            logger.error("%s cannot start without coordination service and scoring_fn", self.worker_id)
             return False
         if register_worker:
             self.coordination_service.register_worker(self.worker_id, self.worker_type, self.capabilities)
@@ -116,7 +116,7 @@ class DistributedWorker:
                     if scored.getScore(nid) is None:
                         new_scores[nid] = (self.scoring_fn(smiles), smiles)
                 except Exception as e:
-                    logger.warning("Error scoring neighbor %s (SMILES: %s): %s", nid, smiles, e)
+                    logger.warning("scoring_fn failed for node %s (%r): %s — neighbour skipped", nid, smiles, e)
                     continue
             dt = time.time() - t0
             ok = self.coordination_service.submit_work_results(self.worker_id, work_item, neighbors, new_scores)

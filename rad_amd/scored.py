@@ -21,12 +21,12 @@ class ScoredSet(ABC):
 
     @abstractmethod
     def get_molecules(self, n: int = None):
-        """Get molecules with scores and SMILES in traversal/insertion order."""
+        """(node_id, score, smiles) tuples, oldest first; n limits the count."""
         pass
 
     @abstractmethod
     def get_best_molecules(self, n: int = None):
-        """Get molecules with scores and SMILES sorted by best scores."""
+        """The same tuples ordered by ascending score (lower docking score = better)."""
         pass
 
     @abstractmethod

@@ -1,0 +1,81 @@
+"""BASELINE-size checks of the traversal through size-independent properties (100M x 1024-bit rows
+resident in HBM, n_to_score = 100k), plus oracle parity at 20M where the host copy is affordable."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big(gpu):
+    from rad_amd.device import DeviceIndex
+    idx = DeviceIndex(1024, 8, 16, 64)
+    idx.synth_vectors(100_000_000, seed=20260101, mode=1)
+    idx.synth_graph(seed=777)
+    return idx
+
+
+def _run(idx, Q, nts):
+    from rad_amd.device import DeviceTraversal
+    t = DeviceTraversal(idx, Q, nts)
+    assert t.run() == 0
+    out = [t.results(i) for i in range(Q.shape[0])]
+    st = t.stats()
+    t.close()
+    return out, st
+
+
+def test_fullsize_properties(big, monkeypatch):
+    n, nts = 100_000_000, 100_000
+    rng = np.random.default_rng(11)
+    Q = np.concatenate([big.read_vectors(int(r), 1) for r in rng.integers(0, n, 7)])
+    res, st = _run(big, Q, nts)
+    assert (st.status == 1).all() and (st.n_scored >= nts).all() and (st.n_scored < nts + 16).all()
+    for i, (s, a, o) in enumerate(res):
+        # P1: a node is scored once; slots are valid
+        assert np.unique(s).size == s.size and int(s.max()) < n
+        # P2: the stored integer scores equal an independent gather-Tanimoto (K2) of the same rows
+        ga, go = big.gather(Q[i:i + 1], s, np.array([0, s.size], np.uint64))
+        assert np.array_equal(ga, a) and np.array_equal(go, o)
+        assert (a <= o).all()
+    # P3: stopping earlier yields a prefix of the longer traversal
+    short, st2 = _run(big, Q[:3], 30_000)
+    for i in range(3):
+        k = short[i][0].size
+        assert 30_000 <= k < 30_016
+        for x, y in zip(short[i], res[i]):
+            assert np.array_equal(x, y[:k])
+    # P4: determinism, and independence from the position / size of the batch a query rides in
+    again, _ = _run(big, Q[[4, 0, 0, 2, 6]], nts)
+    for j, i in enumerate([4, 0, 0, 2, 6]):
+        for x, y in zip(again[j], res[i]):
+            assert np.array_equal(x, y)
+    # P5: the one-traversal-per-wave kernel gives the same answer as the four-per-wave kernel
+    monkeypatch.setenv("RADHIP_NO_TRAV4", "1")
+    other, _ = _run(big, Q[:2], nts)
+    for i in range(2):
+        for x, y in zip(other[i], res[i]):
+            assert np.array_equal(x, y)
+
+
+def test_oracle_parity_at_20m(gpu, oracle):
+    from rad_amd.device import DeviceIndex, DeviceTraversal
+    n, nts = 20_000_000, 100_000
+    idx = DeviceIndex(1024, 8, 16, 64)
+    idx.synth_vectors(n, seed=5, mode=1)
+    idx.synth_graph(seed=6)
+    X = np.empty((n, 128), np.uint8)
+    for f in range(0, n, 5_000_000):
+        X[f:f + 5_000_000] = idx.read_vectors(f, 5_000_000)
+    levels, adj0, upper_row, adjU = idx.read_graph()
+    inf = idx.info()
+    g = oracle.Graph(n, 16, 8, int(inf.max_level), int(inf.entry), levels, adj0, upper_row, adjU)
+    Q = X[[123, 19_999_999, 7_654_321]].copy()
+    t = DeviceTraversal(idx, Q, nts, log_pops=True)
+    assert t.run() == 0
+    for i in range(3):
+        want = oracle.rad_traverse(g, X, Q[i], nts)
+        s, a, o = t.results(i)
+        nodes, lv = t.pop_log(i)
+        assert np.array_equal(nodes, want.pop_nodes) and np.array_equal(lv, want.pop_levels)
+        assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt)

@@ -535,9 +535,14 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint4 *__restrict__ fp,
                                                    const uint32_t *__restrict__ qpop,
                                                    uint32_t *__restrict__ and_out,
                                                    uint32_t *__restrict__ or_out) {
-    constexpr int RPB = 256 / LPR;  // rows per block pass
-    const int chunk = threadIdx.x % LPR;
-    const int rsub = threadIdx.x / LPR;
+    // A wave owns tiles of 64 consecutive rows: LPR wave-loads of 64/LPR rows each, all in flight
+    // before the first popcount.  After the DPP sums every lane of a row group holds the row's
+    // counts; lane (group, chunk) keeps the result of load #chunk, so the 64 lanes end up with the
+    // 64 rows of the tile and write them with ONE coalesced 256-B store per output array.
+    constexpr int RPL = 64 / LPR;            // rows per wave-load
+    constexpr int BATCH = LPR < 8 ? LPR : 8; // loads in flight per lane
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t chunk = lane % LPR, grp = lane / LPR;
     uint4 q[NQ];
     uint32_t qp[NQ];
 #pragma unroll
@@ -545,19 +550,44 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint4 *__restrict__ fp,
         q[i] = queries[i * LPR + chunk];
         qp[i] = qpop[i];
     }
-    const uint64_t n_groups = (count + RPB - 1) / RPB;
-    for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-        const uint64_t r = g * RPB + rsub;
-        const bool ok = r < count;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (ok) v = fp[(first + r) * LPR + chunk];
-        const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v));
+    const uint64_t n_tiles = (count + 63) / 64;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint64_t r0 = tile * 64;
+        uint32_t keep_a[NQ], keep_rp = 0;
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const uint32_t a = rh_group_sum<LPR>(rh_popc4_and(v, q[i]));
-            if (ok && chunk == (i % LPR)) {
-                and_out[(uint64_t)i * count + r] = a;
-                or_out[(uint64_t)i * count + r] = qp[i] + rp - a;
+        for (int i = 0; i < NQ; ++i) keep_a[i] = 0;
+#pragma unroll
+        for (int b0 = 0; b0 < LPR; b0 += BATCH) {
+            uint4 v[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const uint64_t r = r0 + (uint64_t)(b0 + u) * RPL + grp;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (r < count) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(&fp[(first + r) * LPR + chunk]));
+                    v[u] = make_uint4(t.x, t.y, t.z, t.w);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v[u]));
+                if ((int)chunk == b0 + u) keep_rp = rp;
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    const uint32_t a = rh_group_sum<LPR>(rh_popc4_and(v[u], q[i]));
+                    if ((int)chunk == b0 + u) keep_a[i] = a;
+                }
+            }
+        }
+        const uint64_t r = r0 + (uint64_t)chunk * RPL + grp;   // the row this lane kept
+        if (r < count) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                and_out[(uint64_t)i * count + r] = keep_a[i];
+                or_out[(uint64_t)i * count + r] = qp[i] + keep_rp - keep_a[i];
             }
         }
     }
@@ -566,8 +596,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint4 *__restrict__ fp,
 template <int LPR>
 static int launch_scan(radhip_index *idx, int nq, uint64_t first, uint64_t count, const uint4 *dq,
                        const uint32_t *dqpop, uint32_t *da, uint32_t *dorr) {
-    const uint64_t rpb = 256 / LPR;
-    uint64_t groups = (count + rpb - 1) / rpb;
+    uint64_t groups = (count + 255) / 256;   // 4 waves x 64-row tiles per block pass
     uint32_t grid = (uint32_t)std::min<uint64_t>(groups, 256ull * 8ull);
     if (grid == 0) grid = 1;
 #define RH_SCAN_CASE(NQV)                                                                       \

@@ -690,25 +690,38 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint4 *__restrict__ f
                                                      const uint32_t *__restrict__ pair_slot,
                                                      uint64_t n_pairs, uint32_t *__restrict__ and_out,
                                                      uint32_t *__restrict__ or_out) {
+    // LPR lanes per pair, four pairs (= four random row gathers) in flight per lane
     constexpr int PPB = 256 / LPR;
+    constexpr int U = 4;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int chunk = threadIdx.x % LPR;
     const int psub = threadIdx.x / LPR;
-    const uint64_t n_groups = (n_pairs + PPB - 1) / PPB;
+    const uint64_t n_groups = (n_pairs + (uint64_t)PPB * U - 1) / ((uint64_t)PPB * U);
     for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-        const uint64_t p = g * PPB + psub;
-        const bool ok = p < n_pairs;
-        uint4 v = make_uint4(0, 0, 0, 0), q = v;
-        uint32_t qi = 0;
-        if (ok) {
-            qi = pair_q[p];
-            v = fp[(uint64_t)pair_slot[p] * LPR + chunk];
-            q = queries[(uint64_t)qi * LPR + chunk];
+        uint4 v[U], q[U];
+        uint32_t qi[U];
+        uint64_t p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            p[u] = (g * U + (uint64_t)u) * PPB + psub;
+            v[u] = make_uint4(0, 0, 0, 0);
+            q[u] = v[u];
+            qi[u] = 0;
+            if (p[u] < n_pairs) {
+                qi[u] = pair_q[p[u]];
+                const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(&fp[(uint64_t)pair_slot[p[u]] * LPR + chunk]));
+                v[u] = make_uint4(t.x, t.y, t.z, t.w);
+                q[u] = queries[(uint64_t)qi[u] * LPR + chunk];
+            }
         }
-        const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v));
-        const uint32_t a = rh_group_sum<LPR>(rh_popc4_and(v, q));
-        if (ok && chunk == 0) {
-            and_out[p] = a;
-            or_out[p] = qpop[qi] + rp - a;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v[u]));
+            const uint32_t a = rh_group_sum<LPR>(rh_popc4_and(v[u], q[u]));
+            if (p[u] < n_pairs && chunk == 0) {
+                and_out[p[u]] = a;
+                or_out[p[u]] = qpop[qi[u]] + rp - a;
+            }
         }
     }
 }
@@ -749,7 +762,8 @@ extern "C" int radhip_tanimoto_gather(radhip_index_t *idx, const uint8_t *querie
     RH_G(hipMemcpyAsync(dpq, pq.data(), n_pairs * 4, hipMemcpyHostToDevice, idx->stream));
     RH_G(hipMemcpyAsync(dps, cand_slots, n_pairs * 4, hipMemcpyHostToDevice, idx->stream));
     const uint64_t ppb = 256 / idx->lpr;
-    uint32_t grid = (uint32_t)std::min<uint64_t>((n_pairs + ppb - 1) / ppb, 256ull * 16ull);
+    uint32_t grid = (uint32_t)std::min<uint64_t>((n_pairs + ppb * 4 - 1) / (ppb * 4), 256ull * 16ull);
+    if (grid == 0) grid = 1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);

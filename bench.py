@@ -11,8 +11,10 @@ device; no dataset or built index can be downloaded here) and are resident in HB
 the timed region starts.
 
 N > 1 (one process per GPU, launched by torch.distributed.run): weak scaling — every rank
-holds its own 100M-row shard of an N x 100M corpus with its shard-local graph and runs the
-same query batch against it; value = expansions of all ranks / max-over-ranks time.
+holds its own 100M-row shard (N x 100M rows in total) with its shard-local graph and runs the
+same query batch against it; the global budget N x n_to_score is split over the shards by the
+per-round RCCL all-gather of frontier scores (rad_amd/sharded.py); value = expansions of all
+ranks / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -105,22 +107,30 @@ def main():
             torch.cuda.synchronize()
 
     n, ndim, M = args.n, args.ndim, args.connectivity
-    n_total = n * world
+    # every shard is an independent n-row corpus (own seed) with its shard-local graph
     idx = DeviceIndex(ndim, M, 2 * M, 64, device=local_rank)
-    idx.synth_vectors(n, seed=20260101, mode=args.corpus_mode, first_row=rank * n, n_total=n_total)
+    idx.synth_vectors(n, seed=20260101 + rank, mode=args.corpus_mode)
     idx.synth_graph(seed=777 + rank)
     info = idx.info()
     B = info.row_stride
     if args.nq <= 0:
         args.nq = idx.traversal_capacity()   # one wavefront row per traversal: fill the chip exactly once
 
-    # query batches: rows of the logical corpus (identical on every rank), a different batch per step
+    # query batches: rows of shard 0's corpus — every rank regenerates them from the closed-form
+    # definition, so all ranks run the SAME queries; a different batch per step
     n_batches = args.warmup + args.steps
     qrng = np.random.default_rng(4242)
     batches = []
+    qsrc = idx if rank == 0 else DeviceIndex(ndim, M, 2 * M, 64, device=local_rank)
     for b in range(n_batches):
         first = int(qrng.integers(0, n - args.nq))
-        batches.append(idx.read_vectors(first, args.nq))
+        if rank == 0:
+            batches.append(idx.read_vectors(first, args.nq))
+        else:
+            qsrc.synth_vectors(args.nq, seed=20260101, mode=args.corpus_mode, first_row=first, n_total=n)
+            batches.append(qsrc.read_vectors(0, args.nq))
+    if rank != 0:
+        qsrc.close()
     # sharded: the global budget is world x n_to_score, split over the shards round by round
     # (rad_amd/sharded.py); the local state is sized with 25 % headroom over the even split
     local_cap = args.n_to_score if world == 1 else args.n_to_score + args.n_to_score // 4

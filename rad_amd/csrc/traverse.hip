@@ -396,13 +396,22 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
             if (isnew) { L.new_slot[rank] = slot; L.new_h[rank] = h; }
             WSYNC();
             constexpr uint32_t RPP = 64 / LPR;  // rows per pass
-            for (uint32_t base = 0; base < nn; base += RPP) {
-                const uint32_t ri = base + lane / LPR;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (ri < nn) v = P.fp[(uint64_t)L.new_slot[ri] * LPR + chunk];
-                const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v));
-                const uint32_t aa = rh_group_sum<LPR>(rh_popc4_and(v, qv));
-                if (ri < nn && chunk == 0) { L.new_and[ri] = aa; L.new_or[ri] = qpop + rp - aa; }
+            // four row gathers in flight per lane before the first popcount
+            for (uint32_t base = 0; base < nn; base += 4u * RPP) {
+                uint4 v[4];
+                uint32_t ri[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ri[u] = base + (uint32_t)u * RPP + lane / LPR;
+                    v[u] = make_uint4(0, 0, 0, 0);
+                    if (ri[u] < nn) v[u] = P.fp[(uint64_t)L.new_slot[ri[u]] * LPR + chunk];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v[u]));
+                    const uint32_t aa = rh_group_sum<LPR>(rh_popc4_and(v[u], qv));
+                    if (ri[u] < nn && chunk == 0) { L.new_and[ri[u]] = aa; L.new_or[ri[u]] = qpop + rp - aa; }
+                }
             }
             WSYNC();
             // finish the new nodes on lanes spread over the wave (so their keys land in

@@ -1,0 +1,140 @@
+"""The reference's own test shapes run against rad_amd with the index built on the
+GPU: the assertions are the reference's (types, lengths, uniqueness, timing bounds, SMILES
+format) — tests/test_hnsw_service.py, test_integration.py, test_service_layer_smiles.py and
+test_end_to_end_smiles.py of keiserlab/rad, with `usearch.index.Index` -> `rad_amd.index.Index`
+and no Redis."""
+import sqlite3
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TEST_SMILES = ["CCO", "CCC", "CC(C)C", "c1ccccc1", "CC(=O)O", "CCN", "CO", "CC"]
+
+
+def _create_test_hnsw(n=100, dim=64, seed=0):
+    """tests/test_hnsw_service.py:13-28 (unseeded there)."""
+    from rad_amd.index import Index
+    rng = np.random.default_rng(seed)
+    packed = np.packbits(rng.integers(0, 2, size=(n, dim), dtype=np.uint8), axis=1)
+    hnsw = Index(ndim=dim, dtype="b1", metric="tanimoto", connectivity=4, expansion_add=20)
+    hnsw.add(np.arange(n), packed)
+    return hnsw
+
+
+def _create_test_database(path, n=100):
+    """tests/test_integration.py:16-50"""
+    con = sqlite3.connect(path)
+    con.execute("CREATE TABLE nodes (node_key INTEGER PRIMARY KEY, smi TEXT NOT NULL)")
+    for i in range(n):
+        base = TEST_SMILES[i % len(TEST_SMILES)]
+        con.execute("INSERT INTO nodes (node_key, smi) VALUES (?, ?)", (i, f"{base}.{i}" if i > 0 else base))
+    con.commit()
+    con.close()
+
+
+def _scoring_fn(smiles):
+    return float(sum(ord(c) for c in smiles) % 100)      # deterministic score in [0, 100)
+
+
+def test_local_service_basics_and_concurrency(gpu):
+    """test_hnsw_service.py: info keys :37-39, non-empty neighbours :45-47, 5 threads x 10 requests
+    :57-113, counters :208-230, post-shutdown behaviour :177-206."""
+    from rad_amd.hnsw_service import LocalHNSWService
+    svc = LocalHNSWService(_create_test_hnsw())
+    info = svc.get_service_info()
+    assert info["service_type"] == "LocalHNSWService" and info["status"] == "running"
+    nb = svc.get_neighbors(0, 0)
+    assert len(nb) > 0 and len(nb) % 2 == 0
+    top = svc.get_top_level_nodes()
+    assert len(top) > 0 and len(top) % 2 == 0
+    errors, done = [], []
+
+    def worker(tid):
+        for i in range(10):
+            try:
+                r = svc.get_neighbors((tid * 10 + i) % 100, 0)
+                assert isinstance(r, list) and len(r) % 2 == 0
+                done.append(1)
+            except Exception as e:  # pragma: no cover
+                errors.append(e)
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(5)]
+    [t.start() for t in th]
+    [t.join(30) for t in th]
+    assert not errors and len(done) == 50
+    s = svc.get_service_info()
+    assert s["request_count"] >= 52 and s["error_count"] == 0
+    hi = svc.get_hnsw_info()
+    assert hi["size"] == 100 and hi["ndim"] == 64 and hi["connectivity"] == 4 and hi["multi"] is False
+    svc.shutdown()
+    assert svc.is_healthy() is False
+    with pytest.raises(RuntimeError):
+        svc.get_neighbors(0, 0)
+
+
+def test_smiles_format_with_and_without_database(gpu, tmp_path):
+    """test_service_layer_smiles.py:101-136 (int/str alternation, non-empty SMILES with a DB) and
+    :150-190 (every SMILES is "" without one)."""
+    from rad_amd.hnsw_service import create_local_hnsw_service
+    hnsw = _create_test_hnsw()
+    db = str(tmp_path / "t.db")
+    _create_test_database(db)
+    svc = create_local_hnsw_service(hnsw, database_path=db)
+    for data in (svc.get_neighbors(0, 0), svc.get_top_level_nodes()):
+        assert len(data) % 2 == 0 and len(data) > 0
+        for i in range(0, len(data), 2):
+            assert isinstance(data[i], int) and isinstance(data[i + 1], str) and data[i + 1] != ""
+    svc.shutdown()
+    plain = create_local_hnsw_service(hnsw)
+    data = plain.get_neighbors(0, 0)
+    assert all(isinstance(data[i], int) and data[i + 1] == "" for i in range(0, len(data), 2))
+    plain.shutdown()
+
+
+def test_integration_traversals(gpu, tmp_path):
+    """test_integration.py: 1 worker, 30 molecules, < 10 s :89-120; 3 workers no duplicate keys
+    :133-163; n_to_score and timeout terminations :202-247; 4 workers / 50 unique :249-277."""
+    from rad_amd.hnsw_service import create_local_hnsw_service
+    from rad_amd.traverser import RADTraverser
+    hnsw = _create_test_hnsw()
+    db = str(tmp_path / "t.db")
+    _create_test_database(db)
+    # single worker
+    trav = RADTraverser(hnsw_service=create_local_hnsw_service(hnsw, database_path=db), scoring_fn=_scoring_fn)
+    trav.prime()
+    t0 = time.time()
+    trav.traverse(n_workers=1, n_to_score=30)
+    assert time.time() - t0 < 10
+    results = list(trav.scored_set)
+    assert len(results) >= 30
+    for key, score in results[:5]:
+        assert isinstance(key, int) and isinstance(score, (int, float)) and 0 <= score <= 100
+    best = trav.get_best_molecules(5)                                   # test_end_to_end_smiles.py:168-182
+    assert all(isinstance(a, int) and isinstance(b, float) and isinstance(c, str) and c != "" for a, b, c in best)
+    assert len(trav.get_molecules(3)) == 3
+    trav.shutdown()
+    # multi worker
+    for n_workers, target in ((3, 40), (4, 50)):
+        t = RADTraverser(hnsw_service=create_local_hnsw_service(hnsw, database_path=db), scoring_fn=_scoring_fn)
+        t.prime()
+        t0 = time.time()
+        t.traverse(n_workers=n_workers, n_to_score=target)
+        assert time.time() - t0 < 15
+        keys = [k for k, _ in t.scored_set]
+        assert len(keys) >= target and len(set(keys)) == len(keys)
+        stats = t.get_traversal_stats()
+        assert stats["coordination"]["scored_molecules"] == len(keys)
+        t.shutdown()
+    # timeout termination
+    slow = RADTraverser(hnsw_service=create_local_hnsw_service(hnsw, database_path=db),
+                        scoring_fn=lambda s: (time.sleep(0.05), 1.0)[1])
+    slow.prime()
+    t0 = time.time()
+    slow.traverse(n_workers=1, timeout=2)
+    assert time.time() - t0 <= 3.5
+    slow.shutdown()
+    with pytest.raises(ValueError):
+        RADTraverser(hnsw_service=create_local_hnsw_service(hnsw), scoring_fn=_scoring_fn).traverse(n_workers=1)

@@ -44,6 +44,10 @@
 // Lazy clearing: bits 31..25 of an entry's value word carry the epoch of the batch that wrote it
 // (0x7F, what the 0xFF memset leaves, is never a live epoch); entries of older epochs read as empty,
 // so re-arming the state for a new batch of queries does not touch the tables (49 GB at bench size).
+// Home bucket of a slot: multiplicative hash.  (A variant that keeps 16 consecutive slots in one
+// 128-B line of the table was measured slower, with and without a cluster-contiguous
+// renumbering of the corpus: profiles/r01/README.md.)
+#define RH_HT_HASH(s) (((s) * 2654435769u) >> ht_shift)
 #define VAL_EPOCH_SHIFT 25
 #define EPOCH_LIMIT 127u
 #define DQ_INIT (1u << 14)
@@ -120,6 +124,24 @@ __device__ __forceinline__ bool ut_test_and_set(unsigned long long *ut, uint32_t
         h = (h + 1u) & mask;
     }
 }
+// Claim visited-table bucket h for the expansion in flight.  `tab` (N words of LDS, 0 = free) is
+// an exact-match open-addressed set of the buckets already claimed by lanes of THIS expansion;
+// it must outlive every claim round of the expansion: a lane that lost bucket h walks on to
+// h+1, which still reads empty in HBM even when another lane won it earlier (entries are
+// stored only after the fingerprints are scored).  Returns true when this lane now owns h (ci =
+// its word, to be zeroed once the entry is stored), false when another lane does.  At most
+// N/2 claims are live at once, so the walk over `tab` always ends.
+template <uint32_t N>
+__device__ __forceinline__ bool claim_bucket(uint32_t *tab, uint32_t h, uint32_t &ci) {
+    const uint32_t tag = h + 1u;
+    uint32_t i = h & (N - 1u);
+    for (;;) {
+        const uint32_t old = atomicCAS(&tab[i], 0u, tag);
+        if (old == 0u) { ci = i; return true; }
+        if (old == tag) return false;
+        i = (i + 1u) & (N - 1u);
+    }
+}
 __device__ __forceinline__ void st_relaxed(uint32_t *p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -131,6 +153,7 @@ struct TravLds {
     uint32_t new_and[64];
     uint32_t new_or[64];
     uint32_t claim[128];
+    uint32_t claimtab[128];   // buckets claimed by the expansion in flight (0 = free)
 };
 
 // ascending in-place bitonic sort of s[0..P), P a power of two, by one wave
@@ -186,6 +209,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
     int32_t status = H->status;
     if (status == 3 && H->n_scored < H->target) status = 0;  // target was raised: resume
     if (status != 0) return;
+    L.claimtab[lane] = 0u; L.claimtab[lane + 64u] = 0u;
 
     uint64_t n_scored = H->n_scored, n_pops = H->n_pops, n_nbr = H->n_nbr, pq_used = H->pq_used,
              n_upper = H->n_upper, n_repivot = H->n_repivot, n_flush = H->n_flush;
@@ -351,11 +375,11 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
         // race is two lanes of THIS expansion wanting the same empty bucket — settled through an
         // LDS claim word.  No atomics reach HBM (they execute memory-side and capped v1).
         bool isnew = false;
-        uint32_t h = 0, val = 0;
+        uint32_t h = 0, val = 0, ci = 0;
         {
             bool pending = go;          // still walking the probe sequence
             bool cand = false;          // stopped at an empty bucket, not yet confirmed
-            if (go) h = (slot * 2654435769u) >> ht_shift;
+            if (go) h = RH_HT_HASH(slot);
             for (;;) {
                 if (pending) {
                     for (;;) {
@@ -366,17 +390,12 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
                     }
                     pending = false;
                 }
-                if (!__ballot(cand)) break;
-                const uint32_t tag = (h << 6) | lane;
-                if (cand) L.claim[h & 127u] = tag;
-                WSYNC();
-                const uint32_t got = cand ? L.claim[h & 127u] : 0u;
-                WSYNC();
                 if (cand) {
-                    if (got == tag) { isnew = true; cand = false; }                    // bucket is mine
-                    else if ((got >> 6) == h) { cand = false; pending = true; h = (h + 1u) & ht_mask; }  // lost it
-                    // else: another bucket shares the claim word — ask again next round
+                    cand = false;
+                    if (claim_bucket<128u>(L.claimtab, h, ci)) isnew = true;                  // bucket is mine
+                    else { pending = true; h = (h + 1u) & ht_mask; }                           // lost it: walk on
                 }
+                if (!__ballot(pending)) break;
             }
         }
         // scored before: re-enqueue on this level unless already visited here
@@ -431,6 +450,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
             n_scored += nn;
             enqueue(mine, key);
         }
+        if (isnew) L.claimtab[ci] = 0u;   // entries are stored: the claims are spent
         if (__ballot(push_old)) {
             unsigned long long key = RH_KEY_INF;
             if (push_old) key = rh_make_key_dev(rh_q24_dev(val & 0xFFFu, (val >> 12) & 0xFFFu), slot, level);
@@ -461,10 +481,10 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
             if (n_upper > ut_limit) { status = RADHIP_E_CAPACITY; return; }
         }
         bool isnew = false;
-        uint32_t h = 0, val = 0;
+        uint32_t h = 0, val = 0, ci = 0;
         {
             bool pending = go, cand = false;
-            if (go) h = (slot * 2654435769u) >> ht_shift;
+            if (go) h = RH_HT_HASH(slot);
             for (;;) {
                 if (pending) {
                     for (;;) {
@@ -475,16 +495,12 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
                     }
                     pending = false;
                 }
-                if (!__ballot(cand)) break;
-                const uint32_t tag = (h << 6) | lane;
-                if (cand) L.claim[h & 127u] = tag;
-                WSYNC();
-                const uint32_t got = cand ? L.claim[h & 127u] : 0u;
-                WSYNC();
                 if (cand) {
-                    if (got == tag) { isnew = true; cand = false; }
-                    else if ((got >> 6) == h) { cand = false; pending = true; h = (h + 1u) & ht_mask; }
+                    cand = false;
+                    if (claim_bucket<128u>(L.claimtab, h, ci)) isnew = true;
+                    else { pending = true; h = (h + 1u) & ht_mask; }
                 }
+                if (!__ballot(pending)) break;
             }
         }
         bool push_old = false;
@@ -527,6 +543,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
             n_scored += nn;
             enqueue(mine, key);
         }
+        if (isnew) L.claimtab[ci] = 0u;
         if (__ballot(push_old)) {
             unsigned long long key = RH_KEY_INF;
             if (push_old) key = rh_make_key_dev(rh_q24_dev(val & 0xFFFu, (val >> 12) & 0xFFFu), slot, level);
@@ -596,7 +613,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
                 if (nl > 0) {
                     push0 = ut_test_and_set(ut, ut_mask, ut_shift, ((unsigned long long)node << 4) | nl, P.epoch);
                 } else {
-                    uint32_t h = (node * 2654435769u) >> ht_shift;
+                    uint32_t h = RH_HT_HASH(node);
                     unsigned long long e;
                     for (;;) {  // node is scored, hence present
                         e = __hip_atomic_load(&ht[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

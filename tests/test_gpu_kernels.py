@@ -223,6 +223,44 @@ def test_traversal_deep_queue_paths(gpu, oracle, kernel, monkeypatch):
         assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt)
 
 
+@pytest.mark.parametrize("kernel,ndim,M,cap0", [("trav4", 1024, 8, 16), ("trav1", 1024, 8, 16), ("trav1", 2048, 32, 64)])
+def test_traversal_crowded_visited_table(gpu, oracle, kernel, ndim, M, cap0, monkeypatch):
+    """Thousands of short traversals whose visited tables end half full (2 * (n_to_score + 64 + n_top)
+    just fits the smallest table of 1024 buckets): lanes of one expansion keep meeting on the same
+    and on neighbouring empty buckets.  Regression test of the in-expansion claim protocol — a lane
+    that loses bucket h and walks on to h+1 must lose h+1 as well when another lane of the same
+    expansion owns it already, or a visited entry is overwritten and its node scored twice."""
+    from rad_amd.device import DeviceTraversal
+    if kernel == "trav1":
+        monkeypatch.setenv("RADHIP_NO_TRAV4", "1")
+    n, nq = 120_000, 4096
+    idx = _mk_index(ndim, M, cap0)
+    idx.synth_vectors(n, seed=31, mode=1)
+    idx.synth_graph(seed=32)
+    X = oracle.synth_rows(0, n, n, ndim, 31, 1)
+    g = oracle.synth_graph(n, M, cap0, 32)
+    n_top = len(idx.get_top_level_nodes())
+    nts = 512 - 64 - n_top
+    assert nts > 200
+    rng = np.random.default_rng(5)
+    Q = X[rng.choice(n, nq, replace=False)].copy()
+    t = DeviceTraversal(idx, Q, nts, log_pops=True)
+    assert t.run() == 0
+    st = t.stats()
+    bad = []
+    for i in range(nq):
+        want = oracle.rad_traverse(g, X, Q[i], nts)
+        s, a, o = t.results(i)
+        nodes, levels = t.pop_log(i)
+        ok = (len(np.unique(s)) == len(s) and np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt)
+              and np.array_equal(o, want.or_cnt) and np.array_equal(nodes, want.pop_nodes)
+              and np.array_equal(levels, want.pop_levels) and st.n_nbr[i] == want.n_nbr)
+        if not ok:
+            bad.append(i)
+    t.close()
+    assert not bad, f"{len(bad)} of {nq} traversals differ from the oracle, first {bad[:8]}"
+
+
 def test_reset_reuses_tables_across_epochs(gpu, oracle):
     """reset() re-arms the state without clearing the visited tables (epoch tags): many batches in a
     row — past the epoch wrap-around — must each match the oracle, on levels 0 and above."""

@@ -85,12 +85,31 @@ def main():
 
     comm = None
     allgather = None
+    exchange_used = args.exchange
     if dist is not None and args.exchange == "rccl":
-        box = [RcclComm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        comm = RcclComm(rank, world, box[0], local_rank)
-        allgather = comm.allgather_u64
-    elif dist is not None:
+        import torch
+        err = ""
+        try:
+            box = [RcclComm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = RcclComm(rank, world, box[0], local_rank)
+            probe = comm.allgather_u64(np.array([rank + 1], np.uint64))
+            if probe.reshape(-1).tolist() != list(range(1, world + 1)):
+                raise RuntimeError(f"RCCL all-gather self-test returned {probe.reshape(-1).tolist()}")
+            allgather = comm.allgather_u64
+        except Exception as e:   # noqa: BLE001 - reported in the JSON line, never silent
+            err = f"{type(e).__name__}: {e}"
+        # all ranks take the same exchange: if RCCL failed anywhere, the 16 B/traversal control
+        # exchange moves to gloo and the JSON line says so (the data path stays on the GPUs)
+        bad = torch.tensor([1 if err else 0])
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            exchange_used = "gloo (RCCL unavailable: " + "; ".join(sorted({x for x in errs if x}))[:300] + ")"
+            allgather = None
+            comm = None
+    if dist is not None and allgather is None:
         import torch
 
         def allgather(a):
@@ -223,8 +242,8 @@ def main():
             "rows_per_gpu": n, "ndim": ndim, "connectivity": M, "nq_per_gpu": args.nq,
             "n_to_score": args.n_to_score, "corpus_mode": args.corpus_mode,
             "parallelism": ("1 process per GPU, corpus sharded by contiguous row range, global n_to_score = "
-                            f"{world} x {args.n_to_score} split over shards by per-round RCCL all-gather of frontier "
-                            "scores + scored counts") if world > 1 else "single GPU",
+                            f"{world} x {args.n_to_score} split over shards by a per-round all-gather of frontier "
+                            f"scores + scored counts, exchange = {exchange_used}") if world > 1 else "single GPU",
             "exchange_rounds_per_step": (exch["rounds"] / max(args.steps + args.warmup, 1)) if world > 1 else 0,
         },
         "evals_per_s": evals_all / elapsed_max,

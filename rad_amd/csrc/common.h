@@ -76,6 +76,15 @@ int rh_ensure_host_graph(radhip_index *idx);       // D2H mirror of a device-gen
 // ------------------------------------------------- device-side primitives --
 #define RH_WAVE 64
 
+// LDS traffic of one wave is executed in issue order: cross-lane hand-offs through LDS inside a
+// wave need only this compiler-level barrier, not __syncthreads()
+#define RH_WAVE_SYNC()                                           \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
+
 __device__ __forceinline__ uint32_t rh_popc4(const uint4 v) {
     return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
 }

@@ -682,6 +682,21 @@ extern "C" int radhip_tanimoto_scan(radhip_index_t *idx, const uint8_t *queries,
 // ---------------------------------------------------- K2: gather-Tanimoto --
 // LPR lanes per (query, candidate) pair: random B-byte row gathers, 16 B per
 // lane, so a 1024-bit row is one 128-B line fetched by 8 adjacent lanes.
+// Per wave and round: W = (64 / LPR) * U consecutive pairs.  Pair ids come in and results go out
+// as whole coalesced lines through LDS — 32-B partial-line stores (what "lane 0 of every
+// group stores its result" makes) cost the HBM ~2 requests each and capped the first version at
+// 26 G pairs/s — and the ids of the next round are fetched while this round's rows are in
+// flight, so a round is one dependent HBM round trip with U row gathers in flight per lane
+// (scripts/hbm_random.hip: 8 in flight at 16 waves/CU reach the 5.6 TB/s the device serves).
+#ifndef RH_GATHER_BLOCKS_PER_CU
+#define RH_GATHER_BLOCKS_PER_CU 6
+#endif
+template <int LPR>
+struct GatherShape {
+    static constexpr int U = LPR >= 8 ? 8 : 4;
+    static constexpr int GPW = 64 / LPR;
+    static constexpr int W = GPW * U;
+};
 template <int LPR>
 __global__ __launch_bounds__(256) void gather_kernel(const uint4 *__restrict__ fp,
                                                      const uint4 *__restrict__ queries,
@@ -690,39 +705,52 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint4 *__restrict__ f
                                                      const uint32_t *__restrict__ pair_slot,
                                                      uint64_t n_pairs, uint32_t *__restrict__ and_out,
                                                      uint32_t *__restrict__ or_out) {
-    // LPR lanes per pair, four pairs (= four random row gathers) in flight per lane
-    constexpr int PPB = 256 / LPR;
-    constexpr int U = 4;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const int chunk = threadIdx.x % LPR;
-    const int psub = threadIdx.x / LPR;
-    const uint64_t n_groups = (n_pairs + (uint64_t)PPB * U - 1) / ((uint64_t)PPB * U);
-    for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-        uint4 v[U], q[U];
-        uint32_t qi[U];
-        uint64_t p[U];
+    constexpr int U = GatherShape<LPR>::U, W = GatherShape<LPR>::W;
+    __shared__ uint32_t s_slot[4][2][W], s_q[4][2][W], s_a[4][W], s_o[4][W];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int chunk = lane % LPR, grp = lane / LPR;
+    const uint64_t n_rounds = (n_pairs + W - 1) / W;
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+    auto stage_ids = [&](uint64_t r, int buf) {
+        for (int i = lane; i < W; i += 64) {
+            const uint64_t p = r * W + i;
+            const bool in = p < n_pairs;
+            s_slot[wv][buf][i] = in ? pair_slot[p] : RADHIP_NO_SLOT;
+            s_q[wv][buf][i] = in ? pair_q[p] : 0u;
+        }
+    };
+    uint64_t r = (uint64_t)blockIdx.x * 4 + wv;
+    int buf = 0;
+    if (r < n_rounds) stage_ids(r, 0);
+    while (r < n_rounds) {
+        RH_WAVE_SYNC();
+        uint32_t sl[U], qi[U];
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { sl[u] = s_slot[wv][buf][grp * U + u]; qi[u] = s_q[wv][buf][grp * U + u]; }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            p[u] = (g * U + (uint64_t)u) * PPB + psub;
             v[u] = make_uint4(0, 0, 0, 0);
-            q[u] = v[u];
-            qi[u] = 0;
-            if (p[u] < n_pairs) {
-                qi[u] = pair_q[p[u]];
-                const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(&fp[(uint64_t)pair_slot[p[u]] * LPR + chunk]));
-                v[u] = make_uint4(t.x, t.y, t.z, t.w);
-                q[u] = queries[(uint64_t)qi[u] * LPR + chunk];
+            if (sl[u] != RADHIP_NO_SLOT) {
+                v[u] = fp[(uint64_t)sl[u] * LPR + chunk];   // plain: a nontemporal load measured 10 % slower here
             }
         }
+        const uint64_t rn = r + n_waves;
+        if (rn < n_rounds) stage_ids(rn, buf ^ 1);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            const uint4 q = queries[(uint64_t)qi[u] * LPR + chunk];   // L2-resident
             const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v[u]));
-            const uint32_t a = rh_group_sum<LPR>(rh_popc4_and(v[u], q[u]));
-            if (p[u] < n_pairs && chunk == 0) {
-                and_out[p[u]] = a;
-                or_out[p[u]] = qpop[qi[u]] + rp - a;
-            }
+            const uint32_t a = rh_group_sum<LPR>(rh_popc4_and(v[u], q));
+            if (chunk == 0) { s_a[wv][grp * U + u] = a; s_o[wv][grp * U + u] = qpop[qi[u]] + rp - a; }
         }
+        RH_WAVE_SYNC();
+        for (int i = lane; i < W; i += 64) {
+            const uint64_t p = r * W + i;
+            if (p < n_pairs) { and_out[p] = s_a[wv][i]; or_out[p] = s_o[wv][i]; }
+        }
+        r = rn;
+        buf ^= 1;
     }
 }
 
@@ -761,8 +789,13 @@ extern "C" int radhip_tanimoto_gather(radhip_index_t *idx, const uint8_t *querie
     RH_G(hipMemcpyAsync(dpop, pop.data(), (size_t)nq * 4, hipMemcpyHostToDevice, idx->stream));
     RH_G(hipMemcpyAsync(dpq, pq.data(), n_pairs * 4, hipMemcpyHostToDevice, idx->stream));
     RH_G(hipMemcpyAsync(dps, cand_slots, n_pairs * 4, hipMemcpyHostToDevice, idx->stream));
-    const uint64_t ppb = 256 / idx->lpr;
-    uint32_t grid = (uint32_t)std::min<uint64_t>((n_pairs + ppb * 4 - 1) / (ppb * 4), 256ull * 16ull);
+    const uint64_t per_block = 4ull * (64 / idx->lpr) * (idx->lpr >= 8 ? 8 : 4);   // GatherShape<LPR>::W x 4 waves
+    // every wave strides over the rounds, so the grid is exactly what is resident at once (6
+    // blocks = 24 waves per CU at 80 VGPRs; 4 and 8 blocks per CU measured 5-7 % slower) — a
+    // larger grid would run its last blocks on a mostly idle chip
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, idx->device);
+    uint32_t grid = (uint32_t)std::min<uint64_t>((n_pairs + per_block - 1) / per_block, (uint64_t)n_cu * RH_GATHER_BLOCKS_PER_CU);
     if (grid == 0) grid = 1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)hipEventCreate(&e0);

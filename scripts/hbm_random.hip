@@ -102,6 +102,27 @@ __global__ __launch_bounds__(256) void sector_insert_kernel(uint4 *buf, uint64_t
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// (e) store flavours for the insert of (c): MODE 0 plain store, 1 nontemporal store, 2 no load at all
+// (pure scatter of 8-B stores), 3 nontemporal load + nontemporal store
+template <int MODE>
+__global__ __launch_bounds__(256) void store_flavour_kernel(unsigned long long *buf, uint64_t n_lines, uint32_t iters, uint32_t *sink) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long acc = 0;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint64_t r = mix(gid * 0x9E3779B97F4A7C15ull + (uint64_t)it);
+        const uint64_t off = (r % n_lines) * 16 + ((r >> 60) & 15);
+        unsigned long long v = r;
+        if (MODE == 0 || MODE == 1) v = __hip_atomic_load(buf + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MODE == 3) v = __builtin_nontemporal_load(buf + off);
+        acc += v;
+        if (off & 1) {
+            if (MODE == 0 || MODE == 2) buf[off] = v + 1;
+            else __builtin_nontemporal_store(v + 1, buf + off);
+        }
+    }
+    if (acc == 0x123456789ull) sink[0] = (uint32_t)acc;
+}
+
 template <typename F>
 static double time_ms(F launch) {
     hipEvent_t a, b;
@@ -156,6 +177,13 @@ int main(int argc, char **argv) {
             printf("sector probe+insert(50%%) %2d-B sectors waves/CU=%2u: %7.1f ms  %6.2f G probes/s (+ %.2f G stores/s)\n", SB, bpc * 4, ms, lines / ms / 1e6, lines / 2 / ms / 1e6); \
         }
         RUN_SI(16) RUN_SI(32) RUN_SI(64)
+#define RUN_SF(MODE, NAME)                                                                                        \
+        {                                                                                                         \
+            double ms = time_ms([&] { store_flavour_kernel<MODE><<<grid, 256>>>((unsigned long long *)buf, n_lines, iters / 8, sink); }); \
+            double lines = (double)grid * 256 * (iters / 8);                                                      \
+            printf("store flavour %-34s waves/CU=%2u: %7.1f ms  %6.2f G lines/s (+ %.2f G stores/s)\n", NAME, bpc * 4, ms, lines / ms / 1e6, lines / 2 / ms / 1e6); \
+        }
+        RUN_SF(0, "load + plain store") RUN_SF(1, "load + nontemporal store") RUN_SF(2, "no load, plain store (scatter)") RUN_SF(3, "nt load + nt store")
         fflush(stdout);
     }
     CK(hipFree(buf)); CK(hipFree(sink));

@@ -119,3 +119,43 @@ def _derived_case(seed):
 @pytest.mark.parametrize("case", [_derived_case(s) for s in range(40)], ids=lambda c: "-".join(str(x) for x in c))
 def test_more_random_graphs(gpu, oracle, monkeypatch, case):
     test_random_graphs_match_oracle(gpu, oracle, monkeypatch, *case)
+
+
+def _builder_case(seed):
+    r = np.random.default_rng(5000 + seed)
+    M = int(r.choice([2, 3, 4, 8, 12, 16, 32]))
+    cap0 = int(r.choice([M, 2 * M]))
+    return dict(seed=seed, n=int(r.integers(2, 1200)), ndim=int(r.choice([16, 64, 200, 1024, 2048])), M=M, cap0=cap0,
+                ef=int(r.choice([1, 4, 20, 64, 200])), max_batch=int(r.choice([1, 3, 64, 1000])),
+                dup=float(r.choice([0.0, 0.5, 0.95])))
+
+
+@pytest.mark.parametrize("c", [_builder_case(s) for s in range(24)], ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_random_builds_and_searches_match_oracle(gpu, oracle, c):
+    """Index.add (GPU insert kernels) and Index.search against the oracle's usearch-shaped builder
+    on rows with many exact duplicates (equal distances everywhere: candidate order is decided by
+    the slot tie-break), tiny expansion_add, batches larger than the index."""
+    from rad_amd.index import Index
+    rng = np.random.default_rng(c["seed"])
+    n, ndim, M, cap0 = c["n"], c["ndim"], c["M"], c["cap0"]
+    X = _random_rows(rng, n, ndim, c["dup"])
+    h = oracle.Hnsw(ndim, M, cap0, c["ef"], seed=c["seed"])
+    h.add(X, max_batch=c["max_batch"])
+    g = h.graph()
+    idx = Index(ndim=ndim, connectivity=M, connectivity_base=cap0, expansion_add=c["ef"], seed=c["seed"],
+                max_batch=c["max_batch"])
+    idx.add(np.arange(n), X)
+    levels, adj0, upper_row, adjU = idx.device_index().read_graph()
+    assert idx.max_level == g.max_level and idx.device_index().info().entry == g.entry
+    assert np.array_equal(levels, g.levels) and np.array_equal(upper_row, g.upper_row)
+    bad = np.nonzero((adj0 != g.adj0).any(1))[0]
+    assert bad.size == 0, f"level-0 rows differ at nodes {bad[:10]}"
+    assert np.array_equal(adjU[:g.adjU.shape[0]], g.adjU)
+    Q = np.concatenate([X[rng.integers(0, n, 4)], _random_rows(rng, 2, ndim, 0.0)])
+    k = int(min(n, rng.choice([1, 5, 30])))
+    ef = int(rng.choice([1, 8, 100]))
+    m = idx.search(Q, count=k, expansion=ef)
+    for i in range(Q.shape[0]):
+        s, a, o, _, _ = oracle.graph_search(g, X, Q[i], k, ef)
+        cnt = int(m.counts[i])
+        assert cnt == s.size and np.array_equal(m.slots[i, :cnt], s), (i, cnt, s.size)

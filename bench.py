@@ -212,6 +212,7 @@ def main():
     avg_launch_ms = k_ms / max(k_launches, 1)
     achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     traffic = None
+    req_bound = None
     prof = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(prof):
         try:
@@ -219,6 +220,15 @@ def main():
                 pj = json.load(f)
             if pj.get("n") == n and pj.get("nq") == args.nq and pj.get("n_to_score") == args.n_to_score:
                 traffic = pj.get("hbm_bytes_per_launch")
+                rb = pj.get("request_bound")
+                if rb and world == 1:
+                    kernel_rate = pops / (k_ms * 1e-3) if k_ms > 0 else 0.0
+                    req_bound = {"ceiling_expansions_per_s": rb["ceiling_expansions_per_s"],
+                                 "kernel_expansions_per_s": kernel_rate,
+                                 "frac": kernel_rate / rb["ceiling_expansions_per_s"],
+                                 "request_equivalents_per_expansion": rb["request_equivalents_per_expansion"],
+                                 "device_random_requests_per_s": rb["device_random_requests_per_s"],
+                                 "source": "profiles/traffic_latest.json (PMC + scripts/hbm_random.hip, measured offline)"}
         except Exception:
             traffic = None
 
@@ -256,6 +266,8 @@ def main():
             # real HBM bytes (PMC, measured offline: profiles/traffic_latest.json) over this run's launch time
             "hbm_real_gbs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None,
             "hbm_real_frac": (traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            # the bound that explains frac: HBM serves random requests at a fixed rate whatever their size
+            "request_bound": req_bound,
         },
     }
 

@@ -124,3 +124,32 @@ def test_reference_traverser_over_rad_amd_index_equals_rad_amd_stack(ref, tmp_pa
         mine.shutdown()
     assert len(ref_mols) >= n_to_score
     assert got == ref_mols
+
+
+def test_reference_http_server_accepts_rad_amd_index(ref, tmp_path):
+    """The reference's FastAPI app (rad/hnsw_server.py:85-135) constructed around a rad_amd Index:
+    /neighbors, /top-level-nodes, /info and /health answer with the index's data (attribute
+    surface rad/hnsw_server.py:148-161 incl. levels_stats)."""
+    import rad.hnsw_server as ref_server
+    from starlette.testclient import TestClient
+    idx, keys, db, z = _index_and_db(tmp_path)
+    app = ref_server.HNSWServerApp(idx, database_path=db)
+    n = len(idx)
+    with TestClient(app.app) as client:
+        assert client.get("/ping").status_code == 200
+        r = client.get("/neighbors/0/0")
+        assert r.status_code == 200
+        row = z["adj0"][0]
+        want = []
+        for s in row[row != 0xFFFFFFFF]:
+            want.extend([int(s), f"C{int(keys[s])}" if s < n - 5 else ""])
+        assert r.json()["neighbors"] == want
+        top = client.get("/top-level-nodes").json()
+        assert top["top_nodes"][0::2] == [int(i) for i in np.flatnonzero(z["levels"] == z["max_level"])]
+        assert top["node_count"] == len(top["top_nodes"]) // 2
+        info = client.get("/info").json()
+        assert info["hnsw_info"]["max_level"] == int(z["max_level"]) and info["hnsw_info"]["size"] == n
+        assert client.get("/health").status_code == 200
+        assert client.get(f"/neighbors/{n}/0").status_code >= 400                           # no such node
+        assert client.get(f"/neighbors/0/{int(z['max_level']) + 1}").status_code >= 400     # level > max_level
+        assert client.get(f"/neighbors/0/{int(z['levels'][0]) + 1}").status_code >= 400 or int(z["levels"][0]) == int(z["max_level"])

@@ -28,6 +28,9 @@ import time
 
 import numpy as np
 
+# the host driver of these boxes only supports dmabuf IPC: RCCL across processes needs it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

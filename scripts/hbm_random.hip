@@ -141,8 +141,10 @@ static double time_ms(F launch) {
 int main(int argc, char **argv) {
     const uint64_t gib = argc > 1 ? strtoull(argv[1], nullptr, 10) : 32;
     const uint64_t bytes = gib << 30, n_lines = bytes / 128;
+    const unsigned alloc_flags = argc > 2 ? (unsigned)strtoul(argv[2], nullptr, 10) : 0u;   // 0 default, 1 fine-grained, 3 uncached
     void *buf; uint32_t *sink;
-    CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&sink, 4));
+    CK(hipExtMallocWithFlags(&buf, bytes, alloc_flags)); CK(hipMalloc(&sink, 4));
+    printf("allocation flags %u (0 default, 1 fine-grained, 3 uncached)\n", alloc_flags);
     CK(hipMemset(buf, 0x5A, bytes));
     printf("buffer %llu GiB, %llu lines of 128 B\n", (unsigned long long)gib, (unsigned long long)n_lines);
     const uint32_t blocks_per_cu[] = {2, 4, 8};

@@ -1,5 +1,6 @@
-"""BASELINE-size checks of the traversal through size-independent properties (100M x 1024-bit rows
-resident in HBM, n_to_score = 100k), plus oracle parity at 20M where the host copy is affordable."""
+"""BASELINE-size checks of the traversal (100M x 1024-bit rows resident in HBM, n_to_score = 100k):
+size-independent properties, and full oracle parity of 48 traversals at 100M (the corpus and graph are
+copied back to the host: 20 GB) and of 3 at 20M."""
 import numpy as np
 import pytest
 
@@ -79,3 +80,40 @@ def test_oracle_parity_at_20m(gpu, oracle):
         nodes, lv = t.pop_log(i)
         assert np.array_equal(nodes, want.pop_nodes) and np.array_equal(lv, want.pop_levels)
         assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt)
+
+
+def test_oracle_parity_at_100m(big, oracle, monkeypatch):
+    """Bit-exact parity with the oracle AT the bench configuration (100M rows, n_to_score = 100k):
+    the corpus and the graph are copied back from HBM (20 GB of host memory) and 48 traversals are
+    compared in full — expansion order, scored order, integer counts — for the four-per-wave
+    kernel, 6 of them for the one-per-wave kernel too."""
+    from rad_amd.device import DeviceTraversal
+    n, nts = 100_000_000, 100_000
+    X = np.empty((n, 128), np.uint8)
+    for f in range(0, n, 10_000_000):
+        X[f:f + 10_000_000] = big.read_vectors(f, 10_000_000)
+    levels, adj0, upper_row, adjU = big.read_graph()
+    inf = big.info()
+    g = oracle.Graph(n, 16, 8, int(inf.max_level), int(inf.entry), levels, adj0, upper_row, adjU)
+    rng = np.random.default_rng(2026)
+    rows = rng.integers(0, n, 48)
+    Q = X[rows].copy()
+    want = [oracle.rad_traverse(g, X, Q[i], nts) for i in range(Q.shape[0])]
+
+    def check(t, idxs):
+        for j, i in enumerate(idxs):
+            s, a, o = t.results(j)
+            nodes, lv = t.pop_log(j)
+            assert np.array_equal(nodes, want[i].pop_nodes) and np.array_equal(lv, want[i].pop_levels), i
+            assert np.array_equal(s, want[i].slots) and np.array_equal(a, want[i].and_cnt) and np.array_equal(o, want[i].or_cnt), i
+
+    t = DeviceTraversal(big, Q, nts, log_pops=True)
+    assert t.run() == 0
+    check(t, range(48))
+    t.close()
+    monkeypatch.setenv("RADHIP_NO_TRAV4", "1")
+    sel = [0, 7, 13, 21, 34, 47]
+    t1 = DeviceTraversal(big, Q[sel], nts, log_pops=True)
+    assert t1.run() == 0
+    check(t1, sel)
+    t1.close()

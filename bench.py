@@ -262,7 +262,7 @@ def main():
         "evals_per_s": evals_all / elapsed_max,
         "evals_per_expansion": evals_all / max(pops_all, 1.0),
         "roofline": {
-            "bound": "hbm", "kernel": "trav4_kernel" if (2 * M <= 16 and M <= 16) else "trav_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": trav.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_launch_ms,
             "launches": k_launches,

@@ -151,7 +151,8 @@ int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64_t count, u
                      uint32_t max_batch);
 /* replaces usearch Index.search(vectors, count) (never called by RAD itself; the same inner
  * loop as add): k nearest of each query by best-first search with expansion ef >= k.
- * out_* are [nq*k]; out_counts[nq]; out_evals/out_pops (optional) count Tanimoto
+ * out_* are [nq*k]; out_counts[nq] (a query whose search reaches fewer than k nodes gets a
+ * shorter row, padded with RADHIP_NO_SLOT / 0); out_evals/out_pops (optional) count Tanimoto
  * evaluations / node expansions per query. */
 int radhip_search(radhip_index_t *idx, const uint8_t *queries, uint32_t nq, uint32_t k, uint32_t ef,
                   uint32_t *out_slots, uint32_t *out_and, uint32_t *out_or, uint32_t *out_counts,
@@ -207,6 +208,10 @@ uint64_t radhip_traversal_state_bytes(const radhip_traversal_t *t);
 /* traversals resident on the device at once (one wavefront each): batch sizes that are a
  * multiple of it avoid a partially filled last round */
 int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t *out);
+/* Which kernel a traversal object was bound to at create time: 4 = four traversals per wavefront
+ * (batches larger than the one-per-wavefront kernel holds resident, rows <= 16 wide), 1 = one per
+ * wavefront with speculative fingerprint gathers (small batches, wide rows).  Same results. */
+int radhip_traversal_kernel(const radhip_traversal_t *t);
 
 /* per-traversal stop targets (each clamped to n_to_score): a traversal parks (status 3) once
  * n_scored >= its target and resumes when the target is raised — the hook the sharded

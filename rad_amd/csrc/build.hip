@@ -318,6 +318,12 @@ __global__ __launch_bounds__(64) void search_kernel(SearchParams P) {
         }
         WSYNC();
     }
+    // fewer than k results (small or disconnected graph): the tail of the row is defined too
+    for (uint32_t i = nk + lane; i < P.k; i += 64) {
+        P.out_slots[(uint64_t)q * P.k + i] = RADHIP_NO_SLOT;
+        P.out_and[(uint64_t)q * P.k + i] = 0u;
+        P.out_or[(uint64_t)q * P.k + i] = 0u;
+    }
     if (lane == 0) {
         P.out_counts[q] = nk;
         P.out_evals[q] = C.evals;

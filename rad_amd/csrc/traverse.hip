@@ -735,6 +735,10 @@ extern "C" int radhip_traversal_destroy(radhip_traversal_t *t) {
     return RADHIP_OK;
 }
 
+static bool trav4_shape_ok(const radhip_index *idx);
+static int trav_forced_kernel();
+static int trav_capacity_of(radhip_index *idx, bool use4, uint32_t *out);
+
 extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queries, uint32_t nq,
                                        uint64_t n_to_score, uint32_t flags, radhip_traversal_t **out) {
     if (!idx || !queries || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
@@ -749,7 +753,16 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     radhip_traversal *t = new (std::nothrow) radhip_traversal();
     if (!t) RH_FAIL(RADHIP_E_NOMEM, "out of host memory");
     t->idx = idx; t->nq = nq; t->n_to_score = n_to_score; t->flags = flags;
-    t->use4 = idx->cap0 <= 16 && idx->M <= 16 && getenv("RADHIP_NO_TRAV4") == nullptr;
+    {
+        const int forced = trav_forced_kernel();
+        t->use4 = trav4_shape_ok(idx) && forced != 1;
+        if (t->use4 && forced != 4) {   // auto: four per wave only for batches trav_kernel cannot hold resident
+            uint32_t cap1 = 0;
+            int rc1 = trav_capacity_of(idx, false, &cap1);
+            if (rc1 != RADHIP_OK) { delete t; return rc1; }
+            t->use4 = nq > cap1;
+        }
+    }
     const uint64_t n_top = idx->n_top;
     if (n_to_score > idx->g_n) n_to_score = idx->g_n;  // cannot score more than exist
     t->n_to_score = n_to_score;
@@ -1017,15 +1030,29 @@ extern "C" int radhip_debug_device_keys(radhip_index_t *idx, const uint32_t *a, 
     return rc;
 }
 
-// how many traversals are resident at once (waves the chip holds for this kernel): batches that
-// are a multiple of it avoid a partially filled last round
-extern "C" int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t *out) {
-    if (!idx || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
-    std::lock_guard<std::mutex> lk(idx->mu);
-    RH_TRY(rh_ensure_device(idx));
+// ---- kernel choice ---------------------------------------------------------------------
+// trav4_kernel packs four traversals into a wavefront (rows <= 16 wide only): the most
+// expansions per HBM request slot when the chip is full.  trav_kernel gives a traversal a whole
+// wavefront and gathers every neighbour's fingerprint speculatively while the probes are in
+// flight: one dependent HBM round trip less per expansion, 2x faster per traversal as long as
+// all of them are resident at once (measured at 100M rows, n_to_score 100k: nq=1 45 vs 80 ms,
+// nq=256 48 vs 123 ms, nq=4096 75 vs 151 ms; nq=16384 ~240 vs 210 ms).  So: four per wave
+// only when the batch is larger than what trav_kernel holds resident.
+// RADHIP_TRAV=1|4 forces a kernel (tests, profiling); RADHIP_NO_TRAV4 is the older spelling of 1.
+static bool trav4_shape_ok(const radhip_index *idx) { return idx->cap0 <= 16 && idx->M <= 16; }
+
+static int trav_forced_kernel() {
+    if (getenv("RADHIP_NO_TRAV4")) return 1;
+    const char *e = getenv("RADHIP_TRAV");
+    if (e && e[0] == '1') return 1;
+    if (e && e[0] == '4') return 4;
+    return 0;
+}
+
+// traversals resident at once for one of the two kernels (device must be ready)
+static int trav_capacity_of(radhip_index *idx, bool use4, uint32_t *out) {
     int per_cu = 0;
     hipError_t e;
-    const bool use4 = idx->cap0 <= 16 && idx->M <= 16 && getenv("RADHIP_NO_TRAV4") == nullptr;
     if (use4) {
         switch (idx->lpr) {
             case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<1>, 64, 0); break;
@@ -1052,3 +1079,16 @@ extern "C" int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t 
     *out = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount * (use4 ? 4u : 1u);
     return RADHIP_OK;
 }
+
+// The largest batch the chip holds resident at once (with the four-per-wave kernel where the
+// index shape allows it): batches that are a multiple of it avoid a partially filled last round
+extern "C" int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t *out) {
+    if (!idx || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_TRY(rh_ensure_device(idx));
+    return trav_capacity_of(idx, trav4_shape_ok(idx) && trav_forced_kernel() != 1, out);
+}
+
+// 4 = trav4_kernel (four traversals per wavefront), 1 = trav_kernel
+extern "C" int radhip_traversal_kernel(const radhip_traversal_t *t) { return t ? (t->use4 ? 4 : 1) : 0; }
+

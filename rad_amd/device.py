@@ -237,6 +237,12 @@ class DeviceTraversal:
     def state_bytes(self) -> int:
         return int(self._L.radhip_traversal_state_bytes(self._h))
 
+    @property
+    def kernel(self) -> str:
+        """The kernel this batch was bound to: four traversals per wavefront for batches larger
+        than the one-per-wavefront kernel holds resident (rows <= 16 wide), else one per wavefront."""
+        return "trav4_kernel" if int(self._L.radhip_traversal_kernel(self._h)) == 4 else "trav_kernel"
+
 
 class RcclComm:
     """RCCL communicator of the C ABI (one process per GPU).  `unique_id()` is called on rank 0;

@@ -209,7 +209,7 @@ class Index:
         check(_lib.lib().radhip_search(self._dev._h, ptr(q), nq, k, ef, ptr(slots), ptr(a), ptr(o),
                                        ptr(counts), ptr(ev), ptr(pp)))
         keys = np.zeros((nq, k), np.uint64)
-        valid = slots != NO_SLOT
+        valid = np.arange(k)[None, :] < counts[:, None]      # rows are padded with NO_SLOT past counts
         keys[valid] = self._keys[slots[valid].astype(np.int64)]
         return Matches(keys, distance_f32(a, o), counts, slots, int(pp.sum()), int(ev.sum()))
 

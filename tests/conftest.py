@@ -28,3 +28,17 @@ def gpu():
     n = _lib.device_count()
     assert n > 0, "no HIP device visible — gpu-marked tests must run on an MI355X"
     return n
+
+
+def pytest_generate_tests(metafunc):
+    # traversal tests that do not name a kernel run twice: with the library's own choice ("auto":
+    # small batches go to the one-per-wavefront kernel) and with the four-per-wavefront kernel forced
+    if "trav_mode" in metafunc.fixturenames:
+        metafunc.parametrize("trav_mode", ["auto", "trav4"], indirect=True)
+
+
+@pytest.fixture
+def trav_mode(request, monkeypatch):
+    if request.param == "trav4":
+        monkeypatch.setenv("RADHIP_TRAV", "4")
+    return request.param

@@ -30,7 +30,7 @@ def _dev(X, g, M, cap0):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 17])
-def test_tiny_indexes_built_on_gpu(gpu, oracle, n):
+def test_tiny_indexes_built_on_gpu(gpu, oracle, trav_mode, n):
     from rad_amd.index import Index
     X = oracle.synth_rows(0, n, n, 1024, 2, 1)
     h = oracle.Hnsw(1024, 8, 16, 32, seed=9)
@@ -46,7 +46,7 @@ def test_tiny_indexes_built_on_gpu(gpu, oracle, n):
 
 
 @pytest.mark.parametrize("nq", [1, 2, 3, 5, 7, 9])
-def test_ragged_batch_sizes(gpu, oracle, nq):
+def test_ragged_batch_sizes(gpu, oracle, trav_mode, nq):
     """Batches that do not fill the four traversal rows of a wavefront."""
     n = 3000
     X = oracle.synth_rows(0, n, n, 1024, 4, 1)
@@ -55,7 +55,7 @@ def test_ragged_batch_sizes(gpu, oracle, nq):
     _check(oracle, idx, g, X, X[100:100 + nq].copy(), 500)
 
 
-def test_single_level_index_every_node_is_top_level(gpu, oracle):
+def test_single_level_index_every_node_is_top_level(gpu, oracle, trav_mode):
     """max_level == 0: get_top_level_nodes returns every node, prime scores all of them and the
     traversal starts on level 0 (rad/traverser.py:157 start level = max(0, max_level - 1))."""
     n, M, cap0 = 150, 8, 16
@@ -72,7 +72,7 @@ def test_single_level_index_every_node_is_top_level(gpu, oracle):
         _check(oracle, idx, g, X, X[[0, 77]].copy(), nts)
 
 
-def test_empty_rows_and_upper_levels(gpu, oracle):
+def test_empty_rows_and_upper_levels(gpu, oracle, trav_mode):
     """Nodes whose adjacency row is empty on some level still descend (stated deviation)."""
     n, M, cap0 = 64, 4, 8
     X = oracle.synth_rows(0, n, n, 256, 8, 0)
@@ -100,7 +100,7 @@ def test_empty_rows_and_upper_levels(gpu, oracle):
 
 
 @pytest.mark.parametrize("ndim", [100, 1000, 1536, 2048])
-def test_odd_dimensions_and_zero_vectors(gpu, oracle, ndim):
+def test_odd_dimensions_and_zero_vectors(gpu, oracle, trav_mode, ndim):
     n = 2500
     rb = (ndim + 7) // 8
     rng = np.random.default_rng(ndim)
@@ -135,3 +135,24 @@ def test_invalid_arguments_are_rejected(gpu, oracle):
         idx.gather(X[:1], np.array([10_000], np.uint32), np.array([0, 1], np.uint64))
     with pytest.raises(RadHipError):
         DeviceIndex(4096, 8)                                        # ndim > 2048
+
+
+def test_search_rows_shorter_than_k_are_padded(gpu, oracle):
+    """A query whose graph search reaches fewer than k nodes gets counts < k and a row padded with
+    NO_SLOT / zero counts (once the tail was whatever the device buffer held)."""
+    from rad_amd.index import Index
+    n, ndim, M = 40, 64, 2
+    X = oracle.synth_rows(0, n, n, ndim, 3, 0)
+    # two components: nodes 0..19 form a ring, 20..39 another; entry in the first
+    levels = np.zeros(n, np.int8)
+    adj0 = np.full((n, 2 * M), NO_SLOT, np.uint32)
+    for i in range(n):
+        base = 0 if i < 20 else 20
+        adj0[i, :2] = [base + (i - base + 1) % 20, base + (i - base + 19) % 20]
+    idx = Index(ndim=ndim, connectivity=M, connectivity_base=2 * M)
+    idx.load_graph(None, X, levels, adj0, np.full(n, NO_SLOT, np.uint32), np.full((1, M), NO_SLOT, np.uint32), 0, 0)
+    for _ in range(3):   # repeated: the tail must not depend on what earlier calls left in device memory
+        m = idx.search(X[:3], count=30, expansion=64)
+        assert (m.counts == 20).all()
+        assert (m.slots[:, 20:] == NO_SLOT).all() and (m.slots[:, :20] < 20).all()
+        assert (m.keys[:, 20:] == 0).all()

@@ -16,9 +16,11 @@ def big(gpu):
     return idx
 
 
-def _run(idx, Q, nts):
+def _run(idx, Q, nts, want_kernel=None):
     from rad_amd.device import DeviceTraversal
     t = DeviceTraversal(idx, Q, nts)
+    if want_kernel:
+        assert t.kernel == want_kernel
     assert t.run() == 0
     out = [t.results(i) for i in range(Q.shape[0])]
     st = t.stats()
@@ -27,6 +29,7 @@ def _run(idx, Q, nts):
 
 
 def test_fullsize_properties(big, monkeypatch):
+    monkeypatch.setenv("RADHIP_TRAV", "4")   # the bench kernel (a full batch selects it by itself)
     n, nts = 100_000_000, 100_000
     rng = np.random.default_rng(11)
     Q = np.concatenate([big.read_vectors(int(r), 1) for r in rng.integers(0, n, 7)])
@@ -52,8 +55,8 @@ def test_fullsize_properties(big, monkeypatch):
         for x, y in zip(again[j], res[i]):
             assert np.array_equal(x, y)
     # P5: the one-traversal-per-wave kernel gives the same answer as the four-per-wave kernel
-    monkeypatch.setenv("RADHIP_NO_TRAV4", "1")
-    other, _ = _run(big, Q[:2], nts)
+    monkeypatch.setenv("RADHIP_TRAV", "1")
+    other, _ = _run(big, Q[:2], nts, "trav_kernel")
     for i in range(2):
         for x, y in zip(other[i], res[i]):
             assert np.array_equal(x, y)
@@ -107,11 +110,12 @@ def test_oracle_parity_at_100m(big, oracle, monkeypatch):
             assert np.array_equal(nodes, want[i].pop_nodes) and np.array_equal(lv, want[i].pop_levels), i
             assert np.array_equal(s, want[i].slots) and np.array_equal(a, want[i].and_cnt) and np.array_equal(o, want[i].or_cnt), i
 
+    monkeypatch.setenv("RADHIP_TRAV", "4")
     t = DeviceTraversal(big, Q, nts, log_pops=True)
-    assert t.run() == 0
+    assert t.kernel == "trav4_kernel" and t.run() == 0
     check(t, range(48))
     t.close()
-    monkeypatch.setenv("RADHIP_NO_TRAV4", "1")
+    monkeypatch.setenv("RADHIP_TRAV", "1")
     sel = [0, 7, 13, 21, 34, 47]
     t1 = DeviceTraversal(big, Q[sel], nts, log_pops=True)
     assert t1.run() == 0

@@ -78,8 +78,7 @@ CASES = [
 @pytest.mark.parametrize("seed,n,ndim,M,cap0,max_level,p_empty,dup_frac,kernel", CASES)
 def test_random_graphs_match_oracle(gpu, oracle, monkeypatch, seed, n, ndim, M, cap0, max_level, p_empty, dup_frac, kernel):
     from rad_amd.device import DeviceIndex, DeviceTraversal
-    if kernel == "trav1":
-        monkeypatch.setenv("RADHIP_NO_TRAV4", "1")
+    monkeypatch.setenv("RADHIP_TRAV", "1" if kernel == "trav1" else "4")
     rng = np.random.default_rng(seed)
     g = _random_graph(oracle, rng, n, M, cap0, max_level, p_empty)
     X = _random_rows(rng, n, ndim, dup_frac)

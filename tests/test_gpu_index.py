@@ -100,7 +100,7 @@ def test_search_matches_oracle_search(gpu, oracle, ndim, n, M, ef_add, k, ef):
 
 
 @pytest.mark.parametrize("tag,M", [("t64", 4), ("t1024", 8)])
-def test_device_traversal_matches_reference_golden(gpu, tag, M):
+def test_device_traversal_matches_reference_golden(gpu, trav_mode, tag, M):
     """trav_kernel vs the reference's own control flow (golden fixtures): expansion order,
     scored order and float32 scores, including heavy score ties on the 64-bit fixture."""
     from rad_amd.index import Index
@@ -124,7 +124,7 @@ def test_device_traversal_matches_reference_golden(gpu, tag, M):
         t.shutdown()
 
 
-def test_drop_in_end_to_end(gpu, oracle, tmp_path):
+def test_drop_in_end_to_end(gpu, oracle, trav_mode, tmp_path):
     """README.md:45-97 workflow with rad_amd substituted: Index.add on the GPU, SQLite SMILES
     join, RADTraverser with a user scoring_fn; then the same traversal with Tanimoto scoring
     entirely on the device gives the identical result."""

@@ -103,7 +103,7 @@ def _check_traversal(oracle, idx, graph, X, Q, n_to_score):
     (64, 1000, 4, 8, 300),
     (1024, 5000, 8, 16, 5000),      # score everything: queue drains
 ])
-def test_traversal_synthetic_graph(gpu, oracle, ndim, n, M, cap0, n_to_score):
+def test_traversal_synthetic_graph(gpu, oracle, trav_mode, ndim, n, M, cap0, n_to_score):
     idx = _mk_index(ndim, M, cap0)
     idx.synth_vectors(n, seed=3, mode=1)
     idx.synth_graph(seed=4)
@@ -114,7 +114,7 @@ def test_traversal_synthetic_graph(gpu, oracle, ndim, n, M, cap0, n_to_score):
 
 
 @pytest.mark.parametrize("ndim,n,M,ef", [(1024, 3000, 8, 64), (64, 1000, 4, 20)])
-def test_traversal_built_graph(gpu, oracle, ndim, n, M, ef):
+def test_traversal_built_graph(gpu, oracle, trav_mode, ndim, n, M, ef):
     """Graph built by the oracle's usearch-shaped builder, loaded via load_graph."""
     X = oracle.synth_rows(0, n, n, ndim, 21, 1 if ndim >= 512 else 0)
     h = oracle.Hnsw(ndim, M, 2 * M, ef, seed=7)
@@ -133,7 +133,7 @@ def test_traversal_built_graph(gpu, oracle, ndim, n, M, ef):
     assert np.array_equal(idx.get_top_level_nodes(), g.top_level())
 
 
-def test_traversal_resume_in_rounds(gpu, oracle):
+def test_traversal_resume_in_rounds(gpu, oracle, trav_mode):
     """Bounded rounds (max_pops) must give the same result as one run."""
     from rad_amd.device import DeviceTraversal
     n, ndim = 20000, 1024
@@ -191,8 +191,7 @@ def test_traversal_deep_queue_paths(gpu, oracle, kernel, monkeypatch):
     """n_to_score large enough that the pivot queue flushes hundreds of sorted runs and re-pivots
     hundreds of times (bench-scale code paths), for both traversal kernels, still bit-exact."""
     from rad_amd.device import DeviceTraversal
-    if kernel == "trav1":
-        monkeypatch.setenv("RADHIP_NO_TRAV4", "1")
+    monkeypatch.setenv("RADHIP_TRAV", "1" if kernel == "trav1" else "4")
     n, ndim, M, cap0, nts = 400_000, 1024, 8, 16, 60_000
     idx = _mk_index(ndim, M, cap0)
     idx.synth_vectors(n, seed=13, mode=1)
@@ -231,8 +230,7 @@ def test_traversal_crowded_visited_table(gpu, oracle, kernel, ndim, M, cap0, mon
     that loses bucket h and walks on to h+1 must lose h+1 as well when another lane of the same
     expansion owns it already, or a visited entry is overwritten and its node scored twice."""
     from rad_amd.device import DeviceTraversal
-    if kernel == "trav1":
-        monkeypatch.setenv("RADHIP_NO_TRAV4", "1")
+    monkeypatch.setenv("RADHIP_TRAV", "1" if kernel == "trav1" else "4")
     n, nq = 120_000, 4096
     idx = _mk_index(ndim, M, cap0)
     idx.synth_vectors(n, seed=31, mode=1)
@@ -261,7 +259,7 @@ def test_traversal_crowded_visited_table(gpu, oracle, kernel, ndim, M, cap0, mon
     assert not bad, f"{len(bad)} of {nq} traversals differ from the oracle, first {bad[:8]}"
 
 
-def test_reset_reuses_tables_across_epochs(gpu, oracle):
+def test_reset_reuses_tables_across_epochs(gpu, oracle, trav_mode):
     """reset() re-arms the state without clearing the visited tables (epoch tags): many batches in a
     row — past the epoch wrap-around — must each match the oracle, on levels 0 and above."""
     from rad_amd.device import DeviceTraversal
@@ -285,3 +283,40 @@ def test_reset_reuses_tables_across_epochs(gpu, oracle):
                 want = oracle.rad_traverse(g, X, Q[i], 400, log_pops=False)
                 s, a, o = t.results(i)
                 assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt), (batch, i)
+
+
+def test_kernel_choice_follows_batch_size(gpu, monkeypatch):
+    """Auto dispatch: one traversal per wavefront while the whole batch is resident with that
+    kernel, four per wavefront beyond; wide rows always one per wavefront; env overrides."""
+    from rad_amd.device import DeviceTraversal
+    monkeypatch.delenv("RADHIP_TRAV", raising=False)
+    monkeypatch.delenv("RADHIP_NO_TRAV4", raising=False)
+    idx = _mk_index(1024, 8, 16)
+    idx.synth_vectors(50_000, seed=1, mode=1)
+    idx.synth_graph(seed=2)
+    cap4 = idx.traversal_capacity()
+    assert cap4 % 4 == 0 and cap4 >= 1024
+    Q = idx.read_vectors(0, 4)
+    t = DeviceTraversal(idx, Q, 100)
+    assert t.kernel == "trav_kernel"
+    t.close()
+    big = idx.read_vectors(0, cap4)
+    t = DeviceTraversal(idx, big, 100)
+    assert t.kernel == "trav4_kernel"
+    assert t.run() == 0
+    t.close()
+    monkeypatch.setenv("RADHIP_TRAV", "4")
+    t = DeviceTraversal(idx, Q, 100)
+    assert t.kernel == "trav4_kernel"
+    t.close()
+    monkeypatch.setenv("RADHIP_TRAV", "1")
+    t = DeviceTraversal(idx, big[:cap4 // 2], 100)
+    assert t.kernel == "trav_kernel"
+    t.close()
+    monkeypatch.delenv("RADHIP_TRAV")
+    wide = _mk_index(1024, 32, 64)
+    wide.synth_vectors(50_000, seed=1, mode=1)
+    wide.synth_graph(seed=2)
+    t = DeviceTraversal(wide, wide.read_vectors(0, 4), 100)
+    assert t.kernel == "trav_kernel"
+    t.close()

@@ -94,7 +94,7 @@ def test_smiles_format_with_and_without_database(gpu, tmp_path):
     plain.shutdown()
 
 
-def test_integration_traversals(gpu, tmp_path):
+def test_integration_traversals(gpu, trav_mode, tmp_path):
     """test_integration.py: 1 worker, 30 molecules, < 10 s :89-120; 3 workers no duplicate keys
     :133-163; n_to_score and timeout terminations :202-247; 4 workers / 50 unique :249-277."""
     from rad_amd.hnsw_service import create_local_hnsw_service

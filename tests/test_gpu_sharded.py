@@ -20,7 +20,7 @@ def _device_shard(O, X, g, M, cap0):
     return idx
 
 
-def test_targets_park_resume_and_frontier(gpu, oracle):
+def test_targets_park_resume_and_frontier(gpu, oracle, trav_mode):
     from rad_amd import _lib
     from rad_amd.device import DeviceTraversal
     from sharded_util import make_shards
@@ -43,7 +43,7 @@ def test_targets_park_resume_and_frontier(gpu, oracle):
     assert set(t.stats().status.tolist()) <= {1, 2}
 
 
-def test_two_shards_federated_rounds_on_one_gpu(gpu, oracle):
+def test_two_shards_federated_rounds_on_one_gpu(gpu, oracle, trav_mode):
     from rad_amd.device import DeviceTraversal
     from rad_amd.sharded import ShardedTraversal, allocate_targets
     from sharded_util import OracleLocalTraversal, make_shards

@@ -209,7 +209,7 @@ uint64_t radhip_traversal_state_bytes(const radhip_traversal_t *t);
  * multiple of it avoid a partially filled last round */
 int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t *out);
 /* Which kernel a traversal object was bound to at create time: 4 = four traversals per wavefront
- * (batches larger than the one-per-wavefront kernel holds resident, rows <= 16 wide), 1 = one per
+ * (batches larger than two resident rounds of the one-per-wavefront kernel, rows <= 16 wide), 1 = one per
  * wavefront with speculative fingerprint gathers (small batches, wide rows).  Same results. */
 int radhip_traversal_kernel(const radhip_traversal_t *t);
 

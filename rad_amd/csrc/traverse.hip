@@ -756,11 +756,11 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     {
         const int forced = trav_forced_kernel();
         t->use4 = trav4_shape_ok(idx) && forced != 1;
-        if (t->use4 && forced != 4) {   // auto: four per wave only for batches trav_kernel cannot hold resident
+        if (t->use4 && forced != 4) {   // auto: four per wave only beyond two resident rounds of trav_kernel
             uint32_t cap1 = 0;
             int rc1 = trav_capacity_of(idx, false, &cap1);
             if (rc1 != RADHIP_OK) { delete t; return rc1; }
-            t->use4 = nq > cap1;
+            t->use4 = nq > 2ull * cap1;
         }
     }
     const uint64_t n_top = idx->n_top;
@@ -1036,8 +1036,9 @@ extern "C" int radhip_debug_device_keys(radhip_index_t *idx, const uint32_t *a, 
 // wavefront and gathers every neighbour's fingerprint speculatively while the probes are in
 // flight: one dependent HBM round trip less per expansion, 2x faster per traversal as long as
 // all of them are resident at once (measured at 100M rows, n_to_score 100k: nq=1 45 vs 80 ms,
-// nq=256 48 vs 123 ms, nq=4096 75 vs 151 ms; nq=16384 ~240 vs 210 ms).  So: four per wave
-// only when the batch is larger than what trav_kernel holds resident.
+// nq=256 48 vs 123 ms, nq=4096 75 vs 151 ms, nq=8192 152 vs 183 ms, nq=12288 190 vs 194 ms,
+// nq=16384 244 vs 218 ms; trav_kernel holds 6144 resident).  So: four per wave only when the
+// batch is larger than two resident rounds of trav_kernel.
 // RADHIP_TRAV=1|4 forces a kernel (tests, profiling); RADHIP_NO_TRAV4 is the older spelling of 1.
 static bool trav4_shape_ok(const radhip_index *idx) { return idx->cap0 <= 16 && idx->M <= 16; }
 

@@ -787,6 +787,8 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
         const uint32_t rpp = 64u / idx->lpr;
         const uint32_t passes = (p2 + rpp - 1u) / rpp;   // p2 = pow2ceil(widest row) = lanes the spread covers
         P.spec_passes = passes <= 2u ? passes : 0u;
+        // RADHIP_SPEC=0: no speculative gathers (profiling knob; measured 2-12 % slower at every batch size)
+        if (getenv("RADHIP_SPEC") && getenv("RADHIP_SPEC")[0] == '0') P.spec_passes = 0u;
     }
     P.ht_log2 = ht_log2; P.ut_log2 = ut_log2; P.scored_cap = scored_cap; P.pq_cap = pq_cap;
     t->hdr_bytes = (size_t)nq * sizeof(TravHeader);

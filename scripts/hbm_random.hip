@@ -123,6 +123,49 @@ __global__ __launch_bounds__(256) void store_flavour_kernel(unsigned long long *
     if (acc == 0x123456789ull) sink[0] = (uint32_t)acc;
 }
 
+// (f) whole-line and half-line random writes, no reads: 8 (or 4) lanes x 16 B into one random line
+template <int LANES>
+__global__ __launch_bounds__(256) void line_write_kernel(uint4 *buf, uint64_t n_lines, uint32_t iters, uint32_t *sink) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t grp = gid / LANES, chunk = gid % LANES;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint64_t line = mix(grp * 0x9E3779B97F4A7C15ull + (uint64_t)it) % n_lines;
+        buf[line * 8 + chunk] = make_uint4((uint32_t)it, (uint32_t)gid, 3u, 4u);
+    }
+    if (gid == 0xFFFFFFFFFFull) sink[0] = 1;
+}
+
+// (g) probe 8 B per lane; the inserts (half of the lanes) are done by QUADS of lanes: for each
+// inserting lane of a quad, its 4 lanes read the 64-B half-line around the entry (16 B each: one
+// coalesced 64-B request, an L2 hit) and write all 64 B back — a fully dirty half-line, which the
+// HBM takes without a read-modify-write
+__global__ __launch_bounds__(256) void quad_insert_kernel(unsigned long long *buf, uint64_t n_lines, uint32_t iters, uint32_t *sink) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, ql = lane & 3;
+    unsigned long long acc = 0;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint64_t r = mix(gid * 0x9E3779B97F4A7C15ull + (uint64_t)it);
+        const uint64_t off = (r % n_lines) * 16 + ((r >> 60) & 15);        // entry index (8-B units)
+        const unsigned long long v = __hip_atomic_load(buf + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc += v;
+        const bool ins = off & 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int src = (lane & ~3) | k;
+            const bool go = __shfl((int)ins, src) != 0;
+            const uint64_t eo = ((uint64_t)(uint32_t)__shfl((int)(off >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)off, src);
+            const unsigned long long nv = ((unsigned long long)(uint32_t)__shfl((int)(v >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src);
+            if (go) {
+                uint4 *hl = reinterpret_cast<uint4 *>(buf + (eo & ~7ull)) + ql;   // my 16 B of the half-line
+                uint4 w = *hl;
+                if (((eo & 7) >> 1) == (uint64_t)ql) { if (eo & 1) { w.z = (uint32_t)nv + 1; w.w = (uint32_t)(nv >> 32); } else { w.x = (uint32_t)nv + 1; w.y = (uint32_t)(nv >> 32); } }
+                *hl = w;
+            }
+        }
+    }
+    if (acc == 0x123456789ull) sink[0] = (uint32_t)acc;
+}
+
 template <typename F>
 static double time_ms(F launch) {
     hipEvent_t a, b;
@@ -184,6 +227,22 @@ int main(int argc, char **argv) {
             double ms = time_ms([&] { store_flavour_kernel<MODE><<<grid, 256>>>((unsigned long long *)buf, n_lines, iters / 8, sink); }); \
             double lines = (double)grid * 256 * (iters / 8);                                                      \
             printf("store flavour %-34s waves/CU=%2u: %7.1f ms  %6.2f G lines/s (+ %.2f G stores/s)\n", NAME, bpc * 4, ms, lines / ms / 1e6, lines / 2 / ms / 1e6); \
+        }
+        {
+            double ms = time_ms([&] { line_write_kernel<8><<<grid, 256>>>((uint4 *)buf, n_lines, iters / 8, sink); });
+            double lines = (double)grid * 256 / 8 * (iters / 8);
+            printf("whole-line (128 B) random writes waves/CU=%2u: %7.1f ms  %6.2f G lines/s  %7.1f GB/s\n", bpc * 4, ms, lines / ms / 1e6, lines * 128 / ms / 1e6);
+            ms = time_ms([&] { line_write_kernel<4><<<grid, 256>>>((uint4 *)buf, n_lines, iters / 8, sink); });
+            lines = (double)grid * 256 / 4 * (iters / 8);
+            printf("half-line (64 B) random writes waves/CU=%2u: %7.1f ms  %6.2f G writes/s\n", bpc * 4, ms, lines / ms / 1e6);
+            ms = time_ms([&] { line_write_kernel<2><<<grid, 256>>>((uint4 *)buf, n_lines, iters / 8, sink); });
+            lines = (double)grid * 256 / 2 * (iters / 8);
+            printf("sector (32 B) random writes waves/CU=%2u: %7.1f ms  %6.2f G writes/s\n", bpc * 4, ms, lines / ms / 1e6);
+        }
+        {
+            double ms = time_ms([&] { quad_insert_kernel<<<grid, 256>>>((unsigned long long *)buf, n_lines, iters / 8, sink); });
+            double lines = (double)grid * 256 * (iters / 8);
+            printf("probe + quad half-line insert(50%%) waves/CU=%2u: %7.1f ms  %6.2f G probes/s (+ %.2f G inserts/s)\n", bpc * 4, ms, lines / ms / 1e6, lines / 2 / ms / 1e6);
         }
         RUN_SF(0, "load + plain store") RUN_SF(1, "load + nontemporal store") RUN_SF(2, "no load, plain store (scatter)") RUN_SF(3, "nt load + nt store")
         fflush(stdout);

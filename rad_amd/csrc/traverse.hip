@@ -766,7 +766,8 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     const uint64_t n_top = idx->n_top;
     if (n_to_score > idx->g_n) n_to_score = idx->g_n;  // cannot score more than exist
     t->n_to_score = n_to_score;
-    const uint64_t scored_cap = n_to_score + 64 + n_top;
+    // a multiple of 16 entries: every traversal's scored list starts on a 128-B line
+    const uint64_t scored_cap = (n_to_score + 64 + n_top + 15) & ~(uint64_t)15;
     const uint32_t ht_log2 = std::max<uint32_t>(10, log2_ceil(2 * scored_cap));
     const uint64_t up_pairs = idx->n_upper_rows + n_top * (uint64_t)(idx->max_level + 1);
     uint64_t ut_need = std::min<uint64_t>(2 * up_pairs + 64, scored_cap * 8 / idx->M + 1024);

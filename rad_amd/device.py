@@ -146,6 +146,12 @@ class TraversalStats:
     n_flush: np.ndarray = None
 
 
+# numpy view of _lib.TravStats (include/rad_hip.h radhip_trav_stats_t)
+_TRAV_STATS_DTYPE = np.dtype([("n_scored", "<u8"), ("n_pops", "<u8"), ("n_nbr", "<u8"), ("n_repivot", "<u8"),
+                              ("n_flush", "<u8"), ("status", "<i4"), ("reserved", "<i4")])
+assert _TRAV_STATS_DTYPE.itemsize == C.sizeof(_lib.TravStats)
+
+
 class DeviceTraversal:
     """nq independent RAD traversals, Tanimoto-scored, state in HBM (radhip_traversal_t)."""
 
@@ -186,12 +192,10 @@ class DeviceTraversal:
     def stats(self) -> TraversalStats:
         arr = (_lib.TravStats * self.nq)()
         check(self._L.radhip_traversal_stats(self._h, arr))
-        return TraversalStats(np.array([s.n_scored for s in arr], np.int64),
-                              np.array([s.n_pops for s in arr], np.int64),
-                              np.array([s.n_nbr for s in arr], np.int64),
-                              np.array([s.status for s in arr], np.int32),
-                              np.array([s.n_repivot for s in arr], np.int64),
-                              np.array([s.n_flush for s in arr], np.int64))
+        rec = np.frombuffer(arr, dtype=_TRAV_STATS_DTYPE, count=self.nq)   # one view, no per-record Python
+        return TraversalStats(rec["n_scored"].astype(np.int64), rec["n_pops"].astype(np.int64),
+                              rec["n_nbr"].astype(np.int64), rec["status"].astype(np.int32),
+                              rec["n_repivot"].astype(np.int64), rec["n_flush"].astype(np.int64))
 
     def results(self, q: int):
         """(slots, and, or) of traversal q in traversal order."""

@@ -36,6 +36,8 @@ def allocate_targets(scored: np.ndarray, frontier: np.ndarray, n_to_score: int,
     frontier = np.asarray(frontier, dtype=np.uint64)
     world, nq = scored.shape
     remaining = n_to_score - scored.sum(0)
+    if (remaining <= 0).all():      # every budget is spent (the common last round): nothing to split
+        return scored.astype(np.uint64), np.ones(nq, bool)
     live = (frontier != KEY_EMPTY) & (scored < local_cap)
     n_live = live.sum(0)
     done = (remaining <= 0) | (n_live == 0)

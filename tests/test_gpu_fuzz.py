@@ -3,11 +3,16 @@ make: random level assignment, ragged and empty adjacency rows, links to far-awa
 and all-zero fingerprints (long runs of equal scores: the queue order is then decided by the
 bytewise order of "{id}:{level}" alone), odd dimensions, every row width the kernels dispatch
 on.  Seeds are fixed: a failure reproduces."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 NO_SLOT = 0xFFFFFFFF
+# RAD_FUZZ_CASES=N widens the derived-case campaigns (default sizes keep the suite at a few seconds)
+N_TRAV_CASES = int(os.environ.get("RAD_FUZZ_CASES", 40))
+N_BUILD_CASES = int(os.environ.get("RAD_FUZZ_CASES", 24))
 
 
 def _random_graph(oracle, rng, n, M, cap0, max_level, p_empty):
@@ -115,7 +120,7 @@ def _derived_case(seed):
     return (2000 + seed, n, ndim, M, cap0, max_level, float(r.choice([0.0, 0.1, 0.4])), float(r.choice([0.0, 0.3, 0.9])), kernel)
 
 
-@pytest.mark.parametrize("case", [_derived_case(s) for s in range(40)], ids=lambda c: "-".join(str(x) for x in c))
+@pytest.mark.parametrize("case", [_derived_case(s) for s in range(N_TRAV_CASES)], ids=lambda c: "-".join(str(x) for x in c))
 def test_more_random_graphs(gpu, oracle, monkeypatch, case):
     test_random_graphs_match_oracle(gpu, oracle, monkeypatch, *case)
 
@@ -129,7 +134,7 @@ def _builder_case(seed):
                 dup=float(r.choice([0.0, 0.5, 0.95])))
 
 
-@pytest.mark.parametrize("c", [_builder_case(s) for s in range(24)], ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+@pytest.mark.parametrize("c", [_builder_case(s) for s in range(N_BUILD_CASES)], ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
 def test_random_builds_and_searches_match_oracle(gpu, oracle, c):
     """Index.add (GPU insert kernels) and Index.search against the oracle's usearch-shaped builder
     on rows with many exact duplicates (equal distances everywhere: candidate order is decided by

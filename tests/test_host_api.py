@@ -313,3 +313,22 @@ def test_index_serves_adjacency_without_gpu(tmp_path):
     idx.save(p)
     idx2 = Index(path=p, view=True, exclude_vectors=True)
     assert [int(x) for x in idx2.get_neighbors(5, 0)] == flat and len(idx2) == n
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under rad_amd/ imports, loads or links it, and
+    bench.py reaches it only inside its cpu_baseline leg."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "rad_amd", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".hip", ".inc", ".h", "Makefile")):
+            text = open(path, encoding="utf-8", errors="replace").read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), path
+            assert "librad_oracle" not in text and not re.search(r"#\s*include[^\n]*oracle", text), path   # comments may cite it
+    bench = open(os.path.join(root, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"\boracle\b.*import|import.*\boracle\b|from oracle", bench)]
+    assert uses, "bench.py's cpu_baseline leg times the oracle"
+    start = bench.index("def cpu_baseline")
+    end = bench.index("\ndef ", start + 1)
+    assert all(start <= u < end for u in uses), "oracle referenced outside cpu_baseline()"

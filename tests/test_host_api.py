@@ -330,5 +330,6 @@ def test_product_never_touches_the_oracle():
     uses = [m.start() for m in re.finditer(r"\boracle\b.*import|import.*\boracle\b|from oracle", bench)]
     assert uses, "bench.py's cpu_baseline leg times the oracle"
     start = bench.index("def cpu_baseline")
-    end = bench.index("\ndef ", start + 1)
+    nxt = bench.find("\ndef ", start + 1)
+    end = nxt if nxt >= 0 else bench.index("\nif __name__", start)
     assert all(start <= u < end for u in uses), "oracle referenced outside cpu_baseline()"

@@ -138,3 +138,77 @@ def test_integration_traversals(gpu, trav_mode, tmp_path):
     slow.shutdown()
     with pytest.raises(ValueError):
         RADTraverser(hnsw_service=create_local_hnsw_service(hnsw), scoring_fn=_scoring_fn).traverse(n_workers=1)
+
+
+def test_service_registry_and_convenience_function(gpu):
+    """test_hnsw_service.py:115-175: named services, default service, listing, shutdown_all; the
+    convenience function registers its service as the default."""
+    from rad_amd.hnsw_service import LocalHNSWService, ServiceRegistry, create_local_hnsw_service, service_registry
+    registry = ServiceRegistry()
+    hnsw = _create_test_hnsw()
+    s1, s2 = LocalHNSWService(hnsw), LocalHNSWService(hnsw)
+    try:
+        registry.register_service("primary", s1, is_default=True)
+        registry.register_service("secondary", s2)
+        assert registry.get_service("primary") is s1 and registry.get_service("secondary") is s2
+        assert registry.get_service() is s1
+        listed = registry.list_services()
+        assert "primary" in listed and "secondary" in listed
+        assert registry.get_service("primary").get_neighbors(0, 0) is not None
+        assert registry.get_service("secondary").get_neighbors(0, 0) is not None
+    finally:
+        registry.shutdown_all()
+    assert not s1.is_healthy() and not s2.is_healthy()
+    service_registry.shutdown_all()
+    svc = create_local_hnsw_service(hnsw)
+    try:
+        assert service_registry.get_service() is svc
+        assert svc.get_neighbors(0, 0) is not None
+        assert svc.get_service_info()["service_type"] == "LocalHNSWService"
+    finally:
+        service_registry.shutdown_all()
+
+
+def test_service_lifecycle(gpu, tmp_path):
+    """test_integration.py:176-200: initialised and healthy after construction, not running after shutdown."""
+    from rad_amd.hnsw_service import create_local_hnsw_service
+    from rad_amd.traverser import RADTraverser
+    hnsw = _create_test_hnsw()
+    db = str(tmp_path / "t.db")
+    _create_test_database(db)
+    trav = RADTraverser(hnsw_service=create_local_hnsw_service(hnsw, database_path=db), scoring_fn=_scoring_fn)
+    assert trav.is_initialized and trav.hnsw_service.is_healthy()
+    trav.shutdown()
+    assert not trav.is_running
+
+
+def test_retrospective_scored_set_and_scoring_interface(gpu, tmp_path):
+    """test_end_to_end_smiles.py:257-321 (scored set returns (int, float, non-empty str) triples, n
+    or all) and :323-360 (the scoring function is called with non-empty SMILES strings only)."""
+    from rad_amd.hnsw_service import create_local_hnsw_service
+    from rad_amd.scored import InProcessScoredSet
+    from rad_amd.traverser import RADTraverser
+    ss = InProcessScoredSet()
+    for node_id, score, smiles in [(1, 85.5, "CCO"), (2, 92.1, "c1ccccc1O"), (3, 78.3, "CC(C)O"),
+                                   (4, 95.7, "c1ccc(N)cc1"), (5, 82.4, "CC(=O)O")]:
+        ss.insert(node_id, score, smiles)
+    mols = ss.get_molecules(3)
+    assert len(mols) == 3
+    for node_id, score, smiles in mols:
+        assert isinstance(node_id, int) and isinstance(score, float) and isinstance(smiles, str) and smiles != ""
+    assert len(ss.get_molecules()) == 5
+    seen = []
+
+    def scoring_fn(smiles):
+        assert isinstance(smiles, str) and len(smiles) > 0
+        assert not (set(smiles.replace(".", "")) - set("CONFClBrcnos()=[]#-+1234567890"))
+        seen.append(smiles)
+        return len(smiles) * 10.0
+    hnsw = _create_test_hnsw()
+    db = str(tmp_path / "t.db")
+    _create_test_database(db)
+    trav = RADTraverser(hnsw_service=create_local_hnsw_service(hnsw, database_path=db), scoring_fn=scoring_fn)
+    trav.prime()
+    trav.traverse(n_workers=1, n_to_score=25)
+    assert len(seen) >= 25
+    trav.shutdown()

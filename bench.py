@@ -4,7 +4,7 @@
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on; it fits
 one GPU): 100M x 1024-bit fingerprints resident in HBM, layered adjacency (connectivity 8,
 level-0 width 16), `nq` independent best-first RAD traversals (Tanimoto-scored; nq defaults to
-the number the device holds resident at once, 16384 on MI355X) each run to n_to_score = 100k.  One "step" = one pass of the hot path over one batch
+twice the number the device holds resident at once: 2 x 16384 on MI355X) each run to n_to_score = 100k.  One "step" = one pass of the hot path over one batch
 of nq synthetic queries: state re-arm (device memsets + query upload) + traversal kernel
 launch(es) to completion.  Corpus and graph are synthetic (closed-form generators on the
 device; no dataset or built index can be downloaded here) and are resident in HBM before
@@ -135,8 +135,12 @@ def main():
     idx.synth_graph(seed=777 + rank)
     info = idx.info()
     B = info.row_stride
-    if args.nq <= 0:
-        args.nq = idx.traversal_capacity()   # one wavefront row per traversal: fill the chip exactly once
+    auto_nq = args.nq <= 0
+    if auto_nq:
+        # two resident rounds: traversals end at different times (12.1-12.7k expansions each), and the
+        # second round's workgroups fill the slots the early finishers leave: +6.5 % over one exactly
+        # resident round (16384 on MI355X); falls back to one round if the state does not fit in HBM
+        args.nq = 2 * idx.traversal_capacity()
 
     # query batches: rows of shard 0's corpus — every rank regenerates them from the closed-form
     # definition, so all ranks run the SAME queries; a different batch per step
@@ -156,7 +160,25 @@ def main():
     # sharded: the global budget is world x n_to_score, split over the shards round by round
     # (rad_amd/sharded.py); the local state is sized with 25 % headroom over the even split
     local_cap = args.n_to_score if world == 1 else args.n_to_score + args.n_to_score // 4
-    trav = DeviceTraversal(idx, batches[0], local_cap)
+    trav = None
+    try:
+        trav = DeviceTraversal(idx, batches[0], local_cap)
+    except _lib.RadHipError as e:
+        if not (auto_nq and e.code == -4):      # RADHIP_E_NOMEM
+            raise
+    if auto_nq:
+        fits = 1 if trav is not None else 0
+        if dist is not None:                    # every rank runs the same batch size
+            import torch
+            f = torch.tensor([fits])
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            fits = int(f.item())
+        if not fits:
+            if trav is not None:
+                trav.close()
+            args.nq //= 2
+            batches = [b[:args.nq] for b in batches]
+            trav = DeviceTraversal(idx, batches[0], local_cap)
     exch = {"rounds": 0, "bytes": 0}
 
     def step(b):

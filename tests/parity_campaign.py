@@ -1,4 +1,5 @@
-"""One-off validation at the bench configuration: N traversals at 100M rows, GPU statistics (scored,
+"""Manual validation campaign (test infrastructure: it uses the oracle; not collected by pytest).
+At the bench configuration: N traversals at 100M rows, GPU statistics (scored,
 expansions, neighbours seen — any divergence from the sequential semantics changes them) against
 the oracle's threaded runner, for both traversal kernels."""
 import os, sys, time

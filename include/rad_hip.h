@@ -129,6 +129,13 @@ int radhip_get_top_level_nodes(const radhip_index_t *idx, uint32_t *out_slots,
 int radhip_tanimoto_scan(radhip_index_t *idx, const uint8_t *queries, uint32_t nq,
                          uint64_t first, uint64_t count, uint32_t *and_out,
                          uint32_t *or_out);
+/* K1 reduced on the chip: the k nearest rows of [first, first+count) for each query, in
+ * (distance, slot) order — the order of a brute-force scan; replaces usearch's exact search
+ * (Index.search(..., exact=True)), which RAD uses for recall figures only.  out_* are [nq*k]
+ * (rows shorter than k are padded with RADHIP_NO_SLOT / 0), out_counts[nq]; 1 <= k <= 1984. */
+int radhip_tanimoto_topk(radhip_index_t *idx, const uint8_t *queries, uint32_t nq, uint32_t k,
+                         uint64_t first, uint64_t count, uint32_t *out_slots, uint32_t *out_and,
+                         uint32_t *out_or, uint32_t *out_counts);
 /* K2: candidate lists.  cand_offsets[nq+1] delimits each query's slots. */
 int radhip_tanimoto_gather(radhip_index_t *idx, const uint8_t *queries, uint32_t nq,
                            const uint32_t *cand_slots, const uint64_t *cand_offsets,

@@ -63,6 +63,7 @@ SIGNATURES = {
     "radhip_tanimoto_scan": (C.c_int, [_P, _P, _U32, _U64, _U64, _P, _P]),
     "radhip_tanimoto_gather": (C.c_int, [_P, _P, _U32, _P, _P, _P, _P]),
     "radhip_last_kernel_ms": (C.c_double, []),
+    "radhip_tanimoto_topk": (C.c_int, [_P, _P, _U32, _U32, _U64, _U64, _P, _P, _P, _P]),
     "radhip_distance_f32": (C.c_float, [_U32, _U32]),
     "radhip_index_add": (C.c_int, [_P, _P, _U64, _U64, _U32]),
     "radhip_search": (C.c_int, [_P, _P, _U32, _U32, _U32, _P, _P, _P, _P, _P, _P]),

@@ -627,6 +627,11 @@ static void stage_queries(const radhip_index *idx, const uint8_t *queries, uint3
     }
 }
 
+void rh_stage_queries(const radhip_index *idx, const uint8_t *queries, uint32_t nq,
+                      std::vector<uint8_t> &padded, std::vector<uint32_t> &pop) {   // for topk.hip
+    stage_queries(idx, queries, nq, padded, pop);
+}
+
 extern "C" int radhip_tanimoto_scan(radhip_index_t *idx, const uint8_t *queries, uint32_t nq,
                                     uint64_t first, uint64_t count, uint32_t *and_out, uint32_t *or_out) {
     if (!idx || !queries || !and_out || !or_out) RH_FAIL(RADHIP_E_INVALID, "null argument");

@@ -123,6 +123,20 @@ class DeviceIndex:
         check(self._L.radhip_tanimoto_scan(self._h, ptr(q), q.shape[0], first, count, ptr(a), ptr(o)))
         return a, o
 
+    def topk(self, queries: np.ndarray, k: int, first: int = 0, count: Optional[int] = None):
+        """K1 reduced on the chip: the k nearest rows of [first, first+count) per query in (distance,
+        slot) order.  Returns (slots [nq, k], and, or, counts); rows shorter than k are padded."""
+        q = _lib.as_rows(queries, self.row_bytes, "queries")
+        if count is None:
+            count = self.info().n - first
+        nq = q.shape[0]
+        s = np.empty((nq, k), np.uint32)
+        a = np.empty((nq, k), np.uint32)
+        o = np.empty((nq, k), np.uint32)
+        c = np.zeros(nq, np.uint32)
+        check(self._L.radhip_tanimoto_topk(self._h, ptr(q), nq, k, first, count, ptr(s), ptr(a), ptr(o), ptr(c)))
+        return s, a, o, c
+
     def gather(self, queries: np.ndarray, cand_slots: np.ndarray, cand_offsets: np.ndarray):
         """K2: (and, or) of query i against cand_slots[cand_offsets[i]:cand_offsets[i+1]]."""
         q = _lib.as_rows(queries, self.row_bytes, "queries")

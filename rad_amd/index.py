@@ -191,13 +191,18 @@ class Index:
             z = np.zeros((nq, 0))
             return Matches(z.astype(np.uint64), z.astype(np.float32), np.zeros(nq, np.uint32), z.astype(np.uint32))
         if exact:
-            a, o = self._dev.scan(q)
-            qk = ((o.astype(np.int64) - a.astype(np.int64)) << 23) // np.maximum(o.astype(np.int64), 1)
-            order = np.lexsort((np.broadcast_to(np.arange(a.shape[1]), a.shape), qk), axis=1)[:, :k]
-            slots = order.astype(np.uint32)
-            aa = np.take_along_axis(a, order, 1)
-            oo = np.take_along_axis(o, order, 1)
-            counts = np.full(nq, k, np.uint32)
+            # brute force on the device, reduced to the k best on the chip (radhip_tanimoto_topk); larger k
+            # than the kernel keeps in LDS falls back to the full scan + a host sort
+            if k <= 1984:
+                slots, aa, oo, counts = self._dev.topk(q, k, 0, len(self))
+            else:
+                a, o = self._dev.scan(q, 0, len(self))
+                qk = ((o.astype(np.int64) - a.astype(np.int64)) << 23) // np.maximum(o.astype(np.int64), 1)
+                order = np.lexsort((np.broadcast_to(np.arange(a.shape[1]), a.shape), qk), axis=1)[:, :k]
+                slots = order.astype(np.uint32)
+                aa = np.take_along_axis(a, order, 1)
+                oo = np.take_along_axis(o, order, 1)
+                counts = np.full(nq, k, np.uint32)
             return Matches(self._keys[slots.astype(np.int64)], distance_f32(aa, oo), counts, slots)
         ef = max(int(expansion or self.expansion_search), k)
         slots = np.full((nq, k), NO_SLOT, np.uint32)

@@ -320,3 +320,42 @@ def test_kernel_choice_follows_batch_size(gpu, monkeypatch):
     t = DeviceTraversal(wide, wide.read_vectors(0, 4), 100)
     assert t.kernel == "trav_kernel"
     t.close()
+
+
+def _brute_topk(oracle, X, q, k, first, count):
+    a, o = oracle.scan(X[first:first + count], q)
+    qk = ((o.astype(np.int64) - a) << 23) // np.maximum(o.astype(np.int64), 1)
+    order = np.lexsort((np.arange(count), qk))[:k]
+    return (order + first).astype(np.uint32), a[order], o[order]
+
+
+@pytest.mark.parametrize("ndim", [64, 200, 1024, 2048])
+@pytest.mark.parametrize("k,nq", [(1, 3), (10, 9), (100, 8), (500, 2), (1984, 1)])
+def test_topk_matches_brute_force(gpu, oracle, ndim, k, nq):
+    """radhip_tanimoto_topk against a brute-force scan in (distance, slot) order: many exact ties
+    (duplicate rows, all-zero rows), sub-ranges, k larger than the range."""
+    rng = np.random.default_rng(ndim * 7 + k)
+    n = 20_011
+    rb = (ndim + 7) // 8
+    bits = rng.random((n, rb * 8)) < (0.5 if ndim <= 64 else 0.07)
+    bits[:, ndim:] = False
+    X = np.ascontiguousarray(np.packbits(bits, axis=1))
+    X[rng.integers(0, n, 3000)] = X[rng.integers(0, n, 3000)]     # duplicates: equal distances, slot decides
+    X[rng.integers(0, n, 50)] = 0
+    Q = X[rng.integers(0, n, nq)].copy()
+    Q[-1] = 0
+    idx = _mk_index(ndim, 8)
+    idx.load_vectors(X)
+    for first, count in ((0, n), (777, 9000), (n - 37, 37), (5, 1)):
+        s, a, o, c = idx.topk(Q, k, first, count)
+        for i in range(nq):
+            ws, wa, wo = _brute_topk(oracle, X, Q[i], k, first, count)
+            m = ws.size
+            assert c[i] == m
+            assert np.array_equal(s[i, :m], ws), (ndim, k, i, first, count)
+            assert np.array_equal(a[i, :m], wa) and np.array_equal(o[i, :m], wo)
+            assert (s[i, m:] == 0xFFFFFFFF).all() and (a[i, m:] == 0).all()
+    with pytest.raises(Exception):
+        idx.topk(Q, 0)
+    with pytest.raises(Exception):
+        idx.topk(Q, 5000)

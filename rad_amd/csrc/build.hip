@@ -12,6 +12,8 @@
 //   graph; reverse-edge requests are applied in (target, level, source) order.
 #include "common.h"
 
+#include <rocprim/rocprim.hpp>   // device radix sort / select for the reverse-edge request list (a utility, not a kernel of the path)
+
 #include <algorithm>
 #include <new>
 
@@ -489,6 +491,24 @@ static int grow_dev(T **ptr, uint64_t old_elems, uint64_t new_elems, hipStream_t
     return RADHIP_OK;
 }
 
+// ---- reverse-edge requests: order by (target, level, source) and group by (target, level), on the
+// device.  A source is a node of the current batch, so (source - batch_start) fits 16 bits and the whole
+// order fits one 52-bit radix key; the request is rebuilt from the key, there is no payload to move.
+__global__ void req_pack_kernel(const uint4 *req, uint64_t n, uint32_t batch_start, unsigned long long *keys) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 r = req[j];
+        keys[j] = ((unsigned long long)r.x << 20) | ((unsigned long long)(r.y & 15u) << 16) | (unsigned long long)(r.z - batch_start);
+    }
+}
+__global__ void req_unpack_kernel(const unsigned long long *keys, uint64_t n, uint32_t batch_start, uint4 *req,
+                                  unsigned char *group_start) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[j];
+        req[j] = make_uint4((uint32_t)(k >> 20), (uint32_t)(k >> 16) & 15u, batch_start + (uint32_t)(k & 0xFFFFull), 0u);
+        group_start[j] = (j == 0 || (keys[j - 1] >> 16) != (k >> 16)) ? 1 : 0;
+    }
+}
+
 extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64_t count, uint64_t seed,
                                 uint32_t max_batch) {
     if (!idx || (!rows && count)) RH_FAIL(RADHIP_E_INVALID, "null argument");
@@ -561,20 +581,28 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
     int32_t *d_status = nullptr;
     unsigned long long *d_req_count = nullptr;
     uint4 *d_req = nullptr;
-    uint32_t *d_goff = nullptr;
-    uint64_t req_cap = 0, goff_cap = 0;
+    uint32_t *d_goff = nullptr, *d_ng = nullptr;
+    unsigned long long *d_keys_a = nullptr, *d_keys_b = nullptr;
+    unsigned char *d_gstart = nullptr;
+    void *d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    uint64_t req_cap = 0;
+    auto free_req = [&]() {
+        void *ps[] = {d_req, d_goff, d_keys_a, d_keys_b, d_gstart, d_tmp};
+        for (void *p : ps) if (p) (void)hipFree(p);
+        d_req = nullptr; d_goff = nullptr; d_keys_a = d_keys_b = nullptr; d_gstart = nullptr; d_tmp = nullptr; tmp_bytes = 0;
+    };
     auto cleanup = [&]() {
         if (d_vis) (void)hipFree(d_vis); if (d_status) (void)hipFree(d_status);
-        if (d_req_count) (void)hipFree(d_req_count); if (d_req) (void)hipFree(d_req);
-        if (d_goff) (void)hipFree(d_goff);
+        if (d_req_count) (void)hipFree(d_req_count); if (d_ng) (void)hipFree(d_ng);
+        free_req();
     };
 #define BH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { radhip_set_error("%s failed: %s", #x, hipGetErrorString(e_)); cleanup(); return e_ == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP; } } while (0)
     BH(hipMalloc((void **)&d_vis, (bmax << vlog2) * 4));
     BH(hipMalloc((void **)&d_status, bmax * 4));
     BH(hipMalloc((void **)&d_req_count, 8));
+    BH(hipMalloc((void **)&d_ng, 4));
 
-    std::vector<uint4> hreq;
-    std::vector<uint32_t> hgoff;
     std::vector<int32_t> hstatus(bmax);
     uint32_t entry = idx->has_graph ? idx->entry : RADHIP_NO_SLOT;
     int32_t max_level = idx->has_graph ? idx->max_level : -1;
@@ -590,10 +618,18 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
             uint64_t need = 0;
             for (uint64_t i = start; i < end; ++i) need += idx->cap0 + (uint64_t)hl[i] * idx->M;
             if (need > req_cap) {
-                if (d_req) (void)hipFree(d_req);
-                d_req = nullptr;
+                free_req();
                 req_cap = need * 2;
                 BH(hipMalloc((void **)&d_req, req_cap * sizeof(uint4)));
+                BH(hipMalloc((void **)&d_keys_a, req_cap * 8));
+                BH(hipMalloc((void **)&d_keys_b, req_cap * 8));
+                BH(hipMalloc((void **)&d_gstart, req_cap));
+                BH(hipMalloc((void **)&d_goff, (req_cap + 1) * 4));
+                size_t t1 = 0, t2 = 0;
+                BH(rocprim::radix_sort_keys(nullptr, t1, d_keys_a, d_keys_b, (size_t)req_cap, 0u, 52u, idx->stream));
+                BH(rocprim::select(nullptr, t2, rocprim::counting_iterator<uint32_t>(0), d_gstart, d_goff, d_ng, (size_t)req_cap, idx->stream));
+                tmp_bytes = std::max(t1, t2) + 256;
+                BH(hipMalloc(&d_tmp, tmp_bytes));
             }
             BH(hipMemsetAsync(d_req_count, 0, 8, idx->stream));
             BuildParams BP;
@@ -619,26 +655,18 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
                 if (hstatus[b] != 0) { cleanup(); RH_FAIL(hstatus[b], "insert of node %llu overflowed its visited table", (unsigned long long)(start + b)); }
             if (nreq > req_cap) { cleanup(); RH_FAIL(RADHIP_E_CAPACITY, "reverse-edge request buffer overflow"); }
             if (nreq) {
-                hreq.resize(nreq);
-                BH(hipMemcpy(hreq.data(), d_req, nreq * sizeof(uint4), hipMemcpyDeviceToHost));
-                std::sort(hreq.begin(), hreq.end(), [](const uint4 &a, const uint4 &b) {
-                    if (a.x != b.x) return a.x < b.x;
-                    if (a.y != b.y) return a.y < b.y;
-                    return a.z < b.z;
-                });
-                hgoff.clear();
-                for (uint64_t r = 0; r < nreq; ++r)
-                    if (r == 0 || hreq[r].x != hreq[r - 1].x || hreq[r].y != hreq[r - 1].y) hgoff.push_back((uint32_t)r);
-                const uint32_t ng = (uint32_t)hgoff.size();
-                hgoff.push_back((uint32_t)nreq);
-                if (hgoff.size() > goff_cap) {
-                    if (d_goff) (void)hipFree(d_goff);
-                    d_goff = nullptr;
-                    goff_cap = hgoff.size() * 2;
-                    BH(hipMalloc((void **)&d_goff, goff_cap * 4));
-                }
-                BH(hipMemcpyAsync(d_req, hreq.data(), nreq * sizeof(uint4), hipMemcpyHostToDevice, idx->stream));
-                BH(hipMemcpyAsync(d_goff, hgoff.data(), hgoff.size() * 4, hipMemcpyHostToDevice, idx->stream));
+                const uint32_t sgrid = (uint32_t)std::min<uint64_t>((nreq + 255) / 256, 4096);
+                hipLaunchKernelGGL(req_pack_kernel, dim3(sgrid), dim3(256), 0, idx->stream, d_req, (uint64_t)nreq, (uint32_t)start, d_keys_a);
+                size_t tb = tmp_bytes;
+                BH(rocprim::radix_sort_keys(d_tmp, tb, d_keys_a, d_keys_b, (size_t)nreq, 0u, 52u, idx->stream));
+                hipLaunchKernelGGL(req_unpack_kernel, dim3(sgrid), dim3(256), 0, idx->stream, d_keys_b, (uint64_t)nreq, (uint32_t)start, d_req, d_gstart);
+                tb = tmp_bytes;
+                BH(rocprim::select(d_tmp, tb, rocprim::counting_iterator<uint32_t>(0), d_gstart, d_goff, d_ng, (size_t)nreq, idx->stream));
+                uint32_t ng = 0;
+                BH(hipMemcpyAsync(&ng, d_ng, 4, hipMemcpyDeviceToHost, idx->stream));
+                BH(hipStreamSynchronize(idx->stream));
+                const uint32_t nreq32 = (uint32_t)nreq;
+                BH(hipMemcpyAsync(d_goff + ng, &nreq32, 4, hipMemcpyHostToDevice, idx->stream));
                 ReverseParams RP;
                 RP.G = make_view(idx); RP.req = d_req; RP.group_off = d_goff; RP.n_groups = ng;
                 const size_t rlds = wave_lds_bytes(64);

@@ -155,7 +155,7 @@ __device__ uint32_t search_layer(const GraphView &G, const uint4 qv, uint32_t qp
         C.evals += nn;
         // keys of the new candidates, one per lane (lane < nn)
         unsigned long long key = BK_INF;
-        if (lane < nn) key = bk_key(rh_q24(L.u32b[lane], L.u32c[lane]), L.u32a[lane]);
+        if (lane < nn) key = bk_key(rh_q24_dev(L.u32b[lane], L.u32c[lane]), L.u32a[lane]);
         bool keep = lane < nn;
         if (n_top == ef) keep = keep && ((key >> 1) < (L.topA[ef - 1u] >> 1));
         const unsigned long long kb = __ballot(keep);
@@ -221,7 +221,7 @@ __device__ unsigned long long greedy_level(const GraphView &G, const uint4 qv, u
         eval_rows<LPR>(G.fp, qv, qpop, L, nn, lane);
         C.evals += nn;
         unsigned long long key = BK_INF;
-        if (lane < nn) key = bk_key(rh_q24(L.u32b[lane], L.u32c[lane]), L.u32a[lane]);
+        if (lane < nn) key = bk_key(rh_q24_dev(L.u32b[lane], L.u32c[lane]), L.u32a[lane]);
         const unsigned long long best = bk_wave_min_u64(key);
         WSYNC();
         if (best < curk) curk = best; else break;
@@ -249,7 +249,7 @@ __device__ uint32_t select_heuristic(const uint4 *fp, const unsigned long long *
             if (ai < k) av = fp[(uint64_t)sel[ai] * LPR + chunk];
             const uint32_t apop = rh_group_sum<LPR>(rh_popc4(av));
             const uint32_t aa = rh_group_sum<LPR>(rh_popc4_and(av, cv));
-            if (ai < k && rh_q24(aa, apop + cpop - aa) < qc) bad = true;
+            if (ai < k && rh_q24_dev(aa, apop + cpop - aa) < qc) bad = true;
         }
         if (!__ballot(bad)) {
             if (lane == 0) sel[k] = c;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchParams P) {
     WSYNC();
     eval_rows<LPR>(P.G.fp, qv, qpop, L, 1, lane);
     C.evals++;
-    unsigned long long curk = bk_key(rh_q24(L.u32b[0], L.u32c[0]), P.entry);
+    unsigned long long curk = bk_key(rh_q24_dev(L.u32b[0], L.u32c[0]), P.entry);
     WSYNC();
     for (int32_t l = P.max_level; l > 0; --l) curk = greedy_level<LPR>(P.G, qv, qpop, (uint32_t)l, curk, L, C, lane);
     clear_vis<LPR>(vis, P.vlog2, lane);
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64) void build_insert_kernel(BuildParams P) {
     if (lane == 0) L.u32a[0] = P.snap_entry;
     WSYNC();
     eval_rows<LPR>(P.G.fp, qv, qpop, L, 1, lane);
-    unsigned long long curk = bk_key(rh_q24(L.u32b[0], L.u32c[0]), P.snap_entry);
+    unsigned long long curk = bk_key(rh_q24_dev(L.u32b[0], L.u32c[0]), P.snap_entry);
     WSYNC();
     for (int32_t l = P.snap_max_level; l > lv; --l) curk = greedy_level<LPR>(P.G, qv, qpop, (uint32_t)l, curk, L, C, lane);
     for (int32_t l = lv < P.snap_max_level ? lv : P.snap_max_level; l >= 0 && C.status == 0; --l) {
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64) void build_reverse_kernel(ReverseParams P) {
             if (lane < cb) L.u32a[lane] = j < cap ? from_row : s;
             WSYNC();
             eval_rows<LPR>(P.G.fp, tv, tpop, L, cb, lane);
-            if (lane < cb) cand[base + lane] = bk_key(rh_q24(L.u32b[lane], L.u32c[lane]), L.u32a[lane]);
+            if (lane < cb) cand[base + lane] = bk_key(rh_q24_dev(L.u32b[lane], L.u32c[lane]), L.u32a[lane]);
             WSYNC();
         }
         for (uint32_t j = n + lane; j < 128; j += 64) cand[j] = BK_INF;

@@ -72,6 +72,7 @@ struct WaveLds {
     uint32_t *u32a;                   // [64]
     uint32_t *u32b;                   // [64]
     uint32_t *u32c;                   // [64]
+    uint32_t *claim;                  // [128] buckets of the visited table claimed by the expansion in flight
 };
 
 __device__ __forceinline__ WaveLds carve_lds(unsigned char *base, uint32_t ef_cap) {
@@ -82,9 +83,10 @@ __device__ __forceinline__ WaveLds carve_lds(unsigned char *base, uint32_t ef_ca
     L.u32a = reinterpret_cast<uint32_t *>(L.newk + 128);
     L.u32b = L.u32a + 64;
     L.u32c = L.u32b + 64;
+    L.claim = L.u32c + 64;
     return L;
 }
-static size_t wave_lds_bytes(uint32_t ef_cap) { return (size_t)ef_cap * 16 + 128 * 8 + 3 * 64 * 4; }
+static size_t wave_lds_bytes(uint32_t ef_cap) { return (size_t)ef_cap * 16 + 128 * 8 + 3 * 64 * 4 + 128 * 4; }
 
 // Tanimoto of the wave's query chunk `qv` against up to 64 rows whose slots are in
 // L.u32a[0..n); results (and, or) to L.u32b / L.u32c.
@@ -141,8 +143,35 @@ __device__ uint32_t search_layer(const GraphView &G, const uint4 qv, uint32_t qp
         const uint32_t *row = gv_row(G, cur, level, &cap);
         uint32_t nb = RADHIP_NO_SLOT;
         if (lane < cap) nb = row[lane];
+        // Visited test-and-set of the row's slots with plain (L2-served) loads: the table belongs to
+        // this wavefront alone, so the only race is between lanes of this expansion wanting the same
+        // empty bucket — settled by the LDS claim set, as in the traversal kernels (atomics to the
+        // table execute memory-side and were the slowest part of an expansion).
         bool isnew = false;
-        if (nb != RADHIP_NO_SLOT) isnew = vis_test_and_set(vis, vmask, vshift, nb);
+        {
+            bool pending = nb != RADHIP_NO_SLOT, cand = false;
+            uint32_t h = (nb * 2654435769u) >> vshift, ci = 0;
+            for (;;) {
+                if (pending) {
+                    for (;;) {
+                        const uint32_t e = __hip_atomic_load(&vis[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (e == VIS_EMPTY) { cand = true; break; }
+                        if (e == nb) break;
+                        h = (h + 1u) & vmask;
+                    }
+                    pending = false;
+                }
+                if (cand) {
+                    cand = false;
+                    if (claim_bucket<128u>(L.claim, h, ci)) {
+                        isnew = true;
+                        __hip_atomic_store(&vis[h], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else { pending = true; h = (h + 1u) & vmask; }
+                }
+                if (!__ballot(pending)) break;
+            }
+            if (isnew) L.claim[ci] = 0u;
+        }
         const unsigned long long nbal = __ballot(isnew);
         const uint32_t nn = (uint32_t)__popcll(nbal);
         if (nn == 0) continue;
@@ -289,6 +318,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WaveLds L = carve_lds(smem, P.ef_cap);
     const uint32_t lane = threadIdx.x, q = blockIdx.x;
+    L.claim[lane] = 0u; L.claim[lane + 64u] = 0u;
     const uint4 qv = P.queries[(uint64_t)q * LPR + lane % LPR];
     const uint32_t qpop = P.qpop[q];
     uint32_t *vis = P.vis + ((uint64_t)q << P.vlog2);
@@ -354,6 +384,7 @@ __global__ __launch_bounds__(64) void build_insert_kernel(BuildParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WaveLds L = carve_lds(smem, P.ef_cap);
     const uint32_t lane = threadIdx.x;
+    L.claim[lane] = 0u; L.claim[lane + 64u] = 0u;
     const uint32_t i = P.batch_start + blockIdx.x;
     const uint4 qv = P.G.fp[(uint64_t)i * LPR + lane % LPR];
     const uint32_t qpop = rh_group_sum<LPR>(rh_popc4(qv));

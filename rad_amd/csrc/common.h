@@ -138,6 +138,25 @@ __device__ __forceinline__ unsigned long long rh_wave_min_u64(unsigned long long
     return ((unsigned long long)mhi << 32) | mlo;
 }
 
+// Claim visited-table bucket h for the expansion in flight.  `tab` (N words of LDS, 0 = free) is
+// an exact-match open-addressed set of the buckets already claimed by lanes of THIS expansion;
+// it must outlive every claim round of the expansion: a lane that lost bucket h walks on to
+// h+1, which still reads empty in HBM even when another lane won it earlier (entries are
+// stored only after the fingerprints are scored).  Returns true when this lane now owns h (ci =
+// its word, to be zeroed once the entry is stored), false when another lane does.  At most
+// N/2 claims are live at once, so the walk over `tab` always ends.
+template <uint32_t N>
+__device__ __forceinline__ bool claim_bucket(uint32_t *tab, uint32_t h, uint32_t &ci) {
+    const uint32_t tag = h + 1u;
+    uint32_t i = h & (N - 1u);
+    for (;;) {
+        const uint32_t old = atomicCAS(&tab[i], 0u, tag);
+        if (old == 0u) { ci = i; return true; }
+        if (old == tag) return false;
+        i = (i + 1u) & (N - 1u);
+    }
+}
+
 // ---------------------------------------------------- RAD queue key (u64) --
 // Order = Redis ZSET order of rad/priority_queue.py:22-42 for a Tanimoto score:
 //   ascending score, ties by bytes of the member string "{node_id}:{level}".

@@ -124,24 +124,6 @@ __device__ __forceinline__ bool ut_test_and_set(unsigned long long *ut, uint32_t
         h = (h + 1u) & mask;
     }
 }
-// Claim visited-table bucket h for the expansion in flight.  `tab` (N words of LDS, 0 = free) is
-// an exact-match open-addressed set of the buckets already claimed by lanes of THIS expansion;
-// it must outlive every claim round of the expansion: a lane that lost bucket h walks on to
-// h+1, which still reads empty in HBM even when another lane won it earlier (entries are
-// stored only after the fingerprints are scored).  Returns true when this lane now owns h (ci =
-// its word, to be zeroed once the entry is stored), false when another lane does.  At most
-// N/2 claims are live at once, so the walk over `tab` always ends.
-template <uint32_t N>
-__device__ __forceinline__ bool claim_bucket(uint32_t *tab, uint32_t h, uint32_t &ci) {
-    const uint32_t tag = h + 1u;
-    uint32_t i = h & (N - 1u);
-    for (;;) {
-        const uint32_t old = atomicCAS(&tab[i], 0u, tag);
-        if (old == 0u) { ci = i; return true; }
-        if (old == tag) return false;
-        i = (i + 1u) & (N - 1u);
-    }
-}
 __device__ __forceinline__ void st_relaxed(uint32_t *p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench.py — RAD HNSW neighbor-expansion throughput on MI355X.
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on; it fits
-one GPU): 100M x 1024-bit fingerprints resident in HBM, layered adjacency (connectivity 8,
-level-0 width 16), `nq` independent best-first RAD traversals (Tanimoto-scored; nq defaults to
-twice the number the device holds resident at once: 2 x 16384 on MI355X) each run to n_to_score = 100k.  One "step" = one pass of the hot path over one batch
-of nq synthetic queries: state re-arm (device memsets + query upload) + traversal kernel
-launch(es) to completion.  Corpus and graph are synthetic (closed-form generators on the
-device; no dataset or built index can be downloaded here) and are resident in HBM before
-the timed region starts.
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on; it fits one GPU):
+100M x 1024-bit fingerprints resident in HBM; an HNSW graph built over them on the GPU by the
+library's own insert kernels (connectivity 8, level-0 width 16, expansion_add 64: 35 s;
+`--graph synthetic` swaps in a closed-form adjacency generator that is set up in 20 ms); `nq`
+independent best-first RAD traversals (Tanimoto-scored; nq defaults to twice the number the device
+holds resident at once: 2 x 16384 on MI355X), each run to n_to_score = 100k.  One "step" = one pass
+of the hot path over one batch of nq queries: state re-arm (query upload, epoch bump) + traversal
+kernel launch(es) to completion.  The fingerprints are synthetic (closed-form generator on the
+device: no dataset can be downloaded here); corpus, graph and state are resident in HBM before the
+timed region starts.
 
 N > 1 (one process per GPU, launched by torch.distributed.run): weak scaling — every rank
 holds its own 100M-row shard (N x 100M rows in total) with its shard-local graph and runs the
@@ -50,6 +52,10 @@ def parse_args():
                     help="concurrent traversals per GPU per step (0 = what the device holds resident at once)")
     ap.add_argument("--n-to-score", type=int, default=100_000)
     ap.add_argument("--corpus-mode", type=int, default=1, help="0 dense Bernoulli(0.5), 1 clustered sparse")
+    ap.add_argument("--graph", choices=["built", "synthetic"], default="built",
+                    help="adjacency: a real HNSW graph built on the GPU by Index.add over the synthetic rows (default; "
+                         "35 s for 100M) or the closed-form generator on the device (set up in 20 ms)")
+    ap.add_argument("--expansion-add", type=int, default=64, help="expansion_add of the built graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-traversals", type=int, default=0, help="0 = 32 per host core")
     ap.add_argument("--exchange", choices=["rccl", "gloo"], default="rccl",
@@ -130,9 +136,24 @@ def main():
 
     n, ndim, M = args.n, args.ndim, args.connectivity
     # every shard is an independent n-row corpus (own seed) with its shard-local graph
-    idx = DeviceIndex(ndim, M, 2 * M, 64, device=local_rank)
+    idx = DeviceIndex(ndim, M, 2 * M, args.expansion_add, device=local_rank)
     idx.synth_vectors(n, seed=20260101 + rank, mode=args.corpus_mode)
-    idx.synth_graph(seed=777 + rank)
+    if args.graph == "synthetic":
+        idx.synth_graph(seed=777 + rank)
+    else:
+        # a real HNSW graph: the rows go through Index.add's insert kernels (the rows come back to the
+        # host once, add() takes host rows as the reference's does)
+        X = np.empty((n, idx.row_bytes), np.uint8)
+        for f in range(0, n, 4_000_000):
+            c = min(4_000_000, n - f)
+            X[f:f + c] = idx.read_vectors(f, c)
+        idx.close()
+        idx = DeviceIndex(ndim, M, 2 * M, args.expansion_add, device=local_rank)
+        t_build = time.perf_counter()
+        for f in range(0, n, 5_000_000):
+            idx.add_rows(X[f:f + 5_000_000], seed=777 + rank, max_batch=16384)
+        t_build = time.perf_counter() - t_build
+        del X
     info = idx.info()
     B = info.row_stride
     auto_nq = args.nq <= 0
@@ -243,7 +264,8 @@ def main():
         try:
             with open(prof) as f:
                 pj = json.load(f)
-            if pj.get("n") == n and pj.get("nq") == args.nq and pj.get("n_to_score") == args.n_to_score:
+            if (pj.get("n") == n and pj.get("nq") == args.nq and pj.get("n_to_score") == args.n_to_score
+                    and pj.get("graph", "synthetic") == args.graph):
                 traffic = pj.get("hbm_bytes_per_launch")
                 rb = pj.get("request_bound")
                 if rb and world == 1:
@@ -273,7 +295,9 @@ def main():
         "config": {
             "workload": f"{n * world // 1_000_000}M x {ndim}-bit fingerprints ({n // 1_000_000}M per GPU resident in HBM), "
                         f"connectivity={M} (level-0 width {2 * M}), {args.nq} concurrent best-first RAD traversals per GPU "
-                        f"to n_to_score={args.n_to_score}, synthetic corpus+graph",
+                        f"to n_to_score={args.n_to_score}, synthetic corpus, "
+                        + ("closed-form synthetic graph" if args.graph == "synthetic" else
+                           f"HNSW graph built on the GPU (expansion_add={args.expansion_add}, {t_build:.0f} s)"),
             "rows_per_gpu": n, "ndim": ndim, "connectivity": M, "nq_per_gpu": args.nq,
             "n_to_score": args.n_to_score, "corpus_mode": args.corpus_mode,
             "parallelism": ("1 process per GPU, corpus sharded by contiguous row range, global n_to_score = "

@@ -123,6 +123,12 @@ class DeviceIndex:
         check(self._L.radhip_tanimoto_scan(self._h, ptr(q), q.shape[0], first, count, ptr(a), ptr(o)))
         return a, o
 
+    def add_rows(self, rows: np.ndarray, seed: int = 0, max_batch: int = 4096) -> None:
+        """Append rows and link them into the graph on the GPU (radhip_index_add; rad_amd.index.Index.add
+        is the keyed front end of this)."""
+        r = _lib.as_rows(rows, self.row_bytes, "rows")
+        check(self._L.radhip_index_add(self._h, ptr(r), r.shape[0], seed, max_batch))
+
     def topk(self, queries: np.ndarray, k: int, first: int = 0, count: Optional[int] = None):
         """K1 reduced on the chip: the k nearest rows of [first, first+count) per query in (distance,
         slot) order.  Returns (slots [nq, k], and, or, counts); rows shorter than k are padded."""

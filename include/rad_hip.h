@@ -90,7 +90,9 @@ int radhip_index_load_vectors(radhip_index_t *idx, const uint8_t *rows, uint64_t
 /* closed-form synthetic corpus generated on the device (bench configs 2-4:
  * avoids a 12.8 GB host transfer).  rows [first_row, first_row+n) of a
  * logical corpus of n_total rows; mode 0 = Bernoulli(0.5) bits, 1 = clustered
- * sparse (ECFP-like, ~7 % density). */
+ * sparse (ECFP-like, ~7 % density; two cluster levels, random beyond), 2 =
+ * hierarchical sparse (~6 % density; a 4-ary tree of depth ceil(log4 n_total),
+ * rows scattered over its leaves: neighbourhood structure at every scale). */
 int radhip_index_synth_vectors(radhip_index_t *idx, uint64_t n, uint64_t first_row,
                                uint64_t n_total, uint64_t seed, int mode);
 int radhip_index_read_vectors(const radhip_index_t *idx, uint64_t first, uint64_t count,
@@ -113,6 +115,27 @@ int radhip_index_synth_graph(radhip_index_t *idx, uint64_t seed);
 int radhip_index_read_graph(const radhip_index_t *idx, int8_t *levels, uint32_t *adj0,
                             uint32_t *upper_row, uint32_t *adjU);
 
+/* ---- graph-locality layout (optional; performance only) ------------------- */
+/* Renumbers the slots so that graph neighbours get nearby layout ids (greedy graph growing over the
+ * level-0 adjacency, host threads; n_threads = 0 picks the host's share).  The traversal kernels then
+ * keep their visited / scored set (rad/visited.py:17-29, rad/scored.py:37-47) as 2 bits per node in
+ * groups of 384 ids per 128-B line instead of one hash entry per node: the probes of one adjacency row
+ * touch as many lines as the row spans groups.  No result depends on the layout — queue keys, scored
+ * lists and pop logs use slots; any change of the graph or corpus discards it. */
+typedef struct {
+    int32_t valid;          /* a layout is installed                                   */
+    uint32_t group;         /* ids per 128-B line of the grouped table (384)           */
+    uint64_t id_limit;      /* every layout id is below this                           */
+    double groups_per_row;  /* mean groups spanned by a level-0 adjacency row (sampled) */
+    double degree;          /* mean valid entries of a level-0 row (sampled)            */
+    double seconds;         /* host time of the last optimize call                      */
+} radhip_layout_info_t;
+int radhip_index_optimize_layout(radhip_index_t *idx, uint32_t n_threads);
+int radhip_index_layout_info(const radhip_index_t *idx, radhip_layout_info_t *out);
+/* test / tooling hooks: install a given injective layout, read the current one (u32[n]) */
+int radhip_index_set_layout(radhip_index_t *idx, const uint32_t *lid);
+int radhip_index_read_layout(const radhip_index_t *idx, uint32_t *out_lid);
+
 /* replaces index.get_neighbors(node_id, level) — rad/hnsw_service.py:222,
  * rad/hnsw_server.py:483: writes the neighbor slots of (slot, level) in stored
  * order; RADHIP_E_RANGE if the node does not exist on that level. */
@@ -122,6 +145,24 @@ int radhip_get_neighbors(const radhip_index_t *idx, uint32_t slot, int32_t level
  * rad/hnsw_server.py:196: slots with level == max_level, ascending. */
 int radhip_get_top_level_nodes(const radhip_index_t *idx, uint32_t *out_slots,
                                uint64_t cap, uint64_t *out_n);
+
+/* ---- key <-> slot map (host memory only; no device call) ---------------- */
+/* the key half of usearch Index.add(keys, fps) — README.md:58: keys of slots
+ * [first_slot, first_slot+n).  Slots never given a key keep the identity key. */
+int radhip_index_set_keys(radhip_index_t *idx, uint64_t first_slot, const uint64_t *keys, uint64_t n);
+int radhip_index_read_keys(const radhip_index_t *idx, uint64_t first, uint64_t count, uint64_t *out_keys);
+int radhip_keys_from_slots(const radhip_index_t *idx, const uint32_t *slots, uint64_t n, uint64_t *out_keys);
+/* replaces index.get_node_ids_from_keys(keys) — examples/DUDEZ_example.ipynb:408 (and serves the
+ * key join of rad/hnsw_service.py:271 in the other direction): out_slots[i] = slot of keys[i], or
+ * RADHIP_NO_SLOT when the key is unknown (counted in *out_missing, may be NULL).  Binary search over
+ * the slots ordered by key (built on the first lookup after a change); duplicate keys resolve to the
+ * lowest slot. */
+int radhip_slots_from_keys(const radhip_index_t *idx, const uint64_t *keys, uint64_t n, uint32_t *out_slots,
+                           uint64_t *out_missing);
+/* index.get_neighbors(node_id, level) in the reference's own list shape — rad/hnsw_service.py:222,
+ * mock tests/test_redis_auth.py:37-39: out_pairs = [slot, key, slot, key, ...], *out_n = neighbours */
+int radhip_get_neighbors_keyed(const radhip_index_t *idx, uint32_t slot, int32_t level, uint64_t *out_pairs,
+                               uint32_t cap_pairs, uint32_t *out_n);
 
 /* ---- A1: Tanimoto kernels (usearch metric='tanimoto', dtype='b1') ------ */
 /* K1: nq queries x rows [first, first+count): and_out/or_out are [nq*count]

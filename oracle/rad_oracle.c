@@ -780,8 +780,36 @@ static inline uint64_t sparse_word(uint64_t seed, uint64_t a, uint64_t b, int k)
 
 static inline uint64_t syn_nc(uint64_t n) { uint64_t nc = n / SYN_CS; return nc ? nc : 1; }
 
+#define TAG_H0 0x48494552ULL
+#define TAG_HD 0x48494544ULL
+#define TAG_HA 0x48494541ULL
+#define SYN_HMUL 0x9E3779B1ULL
+
+/* mode 2: a 4-ary hierarchy with neighbourhood structure at every scale.  Row r sits on leaf
+ * (r * odd) mod 4^D of a tree of depth D = ceil(log4 n_total) (a bijection: rows that are close in the
+ * tree are scattered over the slots); every tree node keeps 15/16 of its parent's set bits and gains
+ * 1/256 of the clear ones (density stays ~1/17), so two rows whose lowest common ancestor is h levels
+ * up share ~(15/16)^(2h) of their bits: similarity falls smoothly with h instead of in two steps. */
+static int syn_depth(uint64_t n_total) {
+    int d = 1;
+    while (d < 31 && (1ULL << (2 * d)) < n_total) d++;
+    return d;
+}
+static uint64_t synth_word_h(uint64_t seed, uint64_t row, uint64_t n_total, uint32_t w) {
+    const int D = syn_depth(n_total);
+    const uint64_t leaf = (row * SYN_HMUL) & ((1ULL << (2 * D)) - 1ULL);
+    uint64_t x = sparse_word(seed ^ TAG_H0, 0, w, 4);
+    for (int d = 1; d <= D; ++d) {
+        const uint64_t a = leaf >> (2 * (D - d));
+        const uint64_t lv = (uint64_t)d << 40;
+        x = (x & ~sparse_word((seed ^ TAG_HD) + lv, a, w, 4)) | sparse_word((seed ^ TAG_HA) + lv, a, w, 8);
+    }
+    return x;
+}
+
 static uint64_t synth_word(uint64_t seed, uint64_t row, uint64_t n_total, uint32_t w, int mode) {
     if (mode == 0) return h3(seed, row, w);
+    if (mode == 2) return synth_word_h(seed, row, n_total, w);
     uint64_t nc = syn_nc(n_total);
     uint64_t c = row % nc, s = c / SYN_SC;
     uint64_t sb = sparse_word(seed ^ TAG_S, s, w, 4);

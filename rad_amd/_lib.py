@@ -34,6 +34,11 @@ class IndexInfo(C.Structure):
                 ("has_graph", C.c_int32)]
 
 
+class LayoutInfo(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("group", C.c_uint32), ("id_limit", C.c_uint64),
+                ("groups_per_row", C.c_double), ("degree", C.c_double), ("seconds", C.c_double)]
+
+
 class TravStats(C.Structure):
     _fields_ = [("n_scored", C.c_uint64), ("n_pops", C.c_uint64), ("n_nbr", C.c_uint64),
                 ("n_repivot", C.c_uint64), ("n_flush", C.c_uint64),
@@ -60,6 +65,15 @@ SIGNATURES = {
     "radhip_index_read_graph": (C.c_int, [_P, _P, _P, _P, _P]),
     "radhip_get_neighbors": (C.c_int, [_P, _U32, _I32, _P, _U32, C.POINTER(_U32)]),
     "radhip_get_top_level_nodes": (C.c_int, [_P, _P, _U64, C.POINTER(_U64)]),
+    "radhip_index_optimize_layout": (C.c_int, [_P, _U32]),
+    "radhip_index_layout_info": (C.c_int, [_P, C.POINTER(LayoutInfo)]),
+    "radhip_index_set_layout": (C.c_int, [_P, _P]),
+    "radhip_index_read_layout": (C.c_int, [_P, _P]),
+    "radhip_index_set_keys": (C.c_int, [_P, _U64, _P, _U64]),
+    "radhip_index_read_keys": (C.c_int, [_P, _U64, _U64, _P]),
+    "radhip_keys_from_slots": (C.c_int, [_P, _P, _U64, _P]),
+    "radhip_slots_from_keys": (C.c_int, [_P, _P, _U64, _P, C.POINTER(_U64)]),
+    "radhip_get_neighbors_keyed": (C.c_int, [_P, _U32, _I32, _P, _U32, C.POINTER(_U32)]),
     "radhip_tanimoto_scan": (C.c_int, [_P, _P, _U32, _U64, _U64, _P, _P]),
     "radhip_tanimoto_gather": (C.c_int, [_P, _P, _U32, _P, _P, _P, _P]),
     "radhip_last_kernel_ms": (C.c_double, []),

@@ -557,6 +557,7 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
     if (idx->has_vectors != idx->has_graph && (idx->n || idx->g_n))
         RH_FAIL(RADHIP_E_STATE, "add() cannot extend an index that has vectors without a graph (or vice versa)");
     RH_TRY(rh_ensure_device(idx));
+    rh_layout_invalidate(idx);
     const uint64_t first = idx->has_graph ? idx->g_n : 0, total = first + count;
     if (total >= 0xFFFFFFF0ull) RH_FAIL(RADHIP_E_INVALID, "too many nodes");
     const uint32_t lpr = idx->lpr;

@@ -51,6 +51,11 @@ struct radhip_index {
     std::vector<int8_t> h_levels;
     std::vector<uint32_t> h_adj0, h_upper_row, h_adjU, h_top;
     bool h_graph_valid = false;   // host mirror holds the graph
+    // ---- key <-> slot map (usearch keys: README.md:58 add(keys, fps); get_node_ids_from_keys,
+    // examples/DUDEZ_example.ipynb:408): host memory only, sorted view built on first lookup
+    std::vector<uint64_t> h_keys;        // key of every slot (identity where never set)
+    std::vector<uint32_t> h_key_order;   // slots ordered by (key, slot)
+    bool key_order_valid = false;
     std::vector<uint8_t> h_rows;  // staged corpus awaiting upload (freed after)
     bool h_rows_pending = false;
     bool has_graph = false, has_vectors = false;
@@ -67,8 +72,24 @@ struct radhip_index {
     bool d_graph_valid = false;
     uint64_t fp_cap_rows = 0;
     uint64_t device_bytes = 0;
+    // bumped by every call that changes the graph or the corpus (load_graph, synth_graph, add,
+    // load/synth_vectors): traversal objects remember the generation they were sized for
+    uint64_t graph_gen = 0;
+    // ---- graph-locality layout (layout.hip): lid[slot] = position of the slot in an order that keeps
+    // graph neighbours together; the grouped visited table of the traversal kernels is keyed by it.
+    // Results never depend on it (queue keys and outputs use slots), only the table's HBM lines do.
+    std::vector<uint32_t> h_lid;
+    bool layout_valid = false;
+    uint32_t *d_lid = nullptr;      // [g_n]
+    uint2 *d_adjx0 = nullptr;       // [g_n * cap0] {slot, lid} pairs (NO_SLOT padded)
+    uint2 *d_adjxU = nullptr;       // [n_upper_rows * M]
+    uint2 *d_topx = nullptr;        // [n_top]
+    uint64_t lid_limit = 0;         // every lid < lid_limit
+    double layout_lines_per_row = 0.0, layout_degree = 0.0, layout_seconds = 0.0;
     std::mutex mu;
 };
+
+void rh_layout_invalidate(radhip_index *idx);      // layout.hip: the graph changed
 
 int rh_ensure_device(radhip_index *idx);           // lazy HIP init + pending uploads
 int rh_ensure_host_graph(radhip_index *idx);       // D2H mirror of a device-generated graph

@@ -66,9 +66,12 @@ extern "C" int radhip_index_create(uint32_t ndim_bits, uint32_t connectivity,
     return RADHIP_OK;
 }
 
+void rh_layout_free(radhip_index *idx);   // layout.hip
+
 static void free_dev(radhip_index *idx) {
     if (!idx->dev_ready) return;
     (void)hipSetDevice(idx->device);
+    rh_layout_free(idx);
     if (idx->d_fp) (void)hipFree(idx->d_fp);
     if (idx->d_levels) (void)hipFree(idx->d_levels);
     if (idx->d_adj0) (void)hipFree(idx->d_adj0);
@@ -210,6 +213,7 @@ extern "C" int radhip_index_load_vectors(radhip_index_t *idx, const uint8_t *row
     idx->n = n;
     idx->h_rows_pending = true;
     idx->has_vectors = true;
+    idx->graph_gen++;
     return RADHIP_OK;
 }
 
@@ -241,8 +245,33 @@ __host__ __device__ __forceinline__ uint64_t syn_nc(uint64_t n) {
     uint64_t nc = n / SYN_CS;
     return nc ? nc : 1;
 }
+#define SYN_TAG_H0 0x48494552ULL
+#define SYN_TAG_HD 0x48494544ULL
+#define SYN_TAG_HA 0x48494541ULL
+#define SYN_HMUL 0x9E3779B1ULL
+// mode 2: a 4-ary hierarchy with neighbourhood structure at every scale (restated in
+// oracle/rad_oracle.c synth_word_h): row r sits on leaf (r * odd) mod 4^D of a tree of depth
+// D = ceil(log4 n_total); every tree node keeps 15/16 of its parent's set bits and gains 1/256 of the
+// clear ones, so similarity falls smoothly with the height of the lowest common ancestor.
+__host__ __device__ __forceinline__ int syn_depth(uint64_t n_total) {
+    int d = 1;
+    while (d < 31 && (1ULL << (2 * d)) < n_total) d++;
+    return d;
+}
+__device__ __forceinline__ uint64_t syn_word_h(uint64_t seed, uint64_t row, uint64_t n_total, uint32_t w) {
+    const int D = syn_depth(n_total);
+    const uint64_t leaf = (row * SYN_HMUL) & ((1ULL << (2 * D)) - 1ULL);
+    uint64_t x = syn_sparse(seed ^ SYN_TAG_H0, 0, w, 4);
+    for (int d = 1; d <= D; ++d) {
+        const uint64_t a = leaf >> (2 * (D - d));
+        const uint64_t lv = (uint64_t)d << 40;
+        x = (x & ~syn_sparse((seed ^ SYN_TAG_HD) + lv, a, w, 4)) | syn_sparse((seed ^ SYN_TAG_HA) + lv, a, w, 8);
+    }
+    return x;
+}
 __device__ __forceinline__ uint64_t syn_word(uint64_t seed, uint64_t row, uint64_t n_total, uint32_t w, int mode) {
     if (mode == 0) return syn_h3(seed, row, w);
+    if (mode == 2) return syn_word_h(seed, row, n_total, w);
     uint64_t nc = syn_nc(n_total);
     uint64_t c = row % nc, s = c / SYN_SC;
     uint64_t sb = syn_sparse(seed ^ SYN_TAG_S, s, w, 4);
@@ -279,7 +308,7 @@ __global__ void synth_rows_kernel(uint64_t *fp, uint64_t n, uint32_t words_per_s
 extern "C" int radhip_index_synth_vectors(radhip_index_t *idx, uint64_t n, uint64_t first_row,
                                           uint64_t n_total, uint64_t seed, int mode) {
     if (!idx) RH_FAIL(RADHIP_E_INVALID, "null index");
-    if (mode != 0 && mode != 1) RH_FAIL(RADHIP_E_INVALID, "mode must be 0 or 1");
+    if (mode < 0 || mode > 2) RH_FAIL(RADHIP_E_INVALID, "mode must be 0, 1 or 2");
     if (first_row + n > n_total) RH_FAIL(RADHIP_E_INVALID, "rows [first, first+n) exceed n_total");
     std::lock_guard<std::mutex> lk(idx->mu);
     idx->h_rows_pending = false;
@@ -295,6 +324,7 @@ extern "C" int radhip_index_synth_vectors(radhip_index_t *idx, uint64_t n, uint6
     RH_HIP(hipGetLastError());
     RH_HIP(hipStreamSynchronize(idx->stream));
     idx->has_vectors = true;
+    idx->graph_gen++;
     return RADHIP_OK;
 }
 
@@ -355,6 +385,7 @@ extern "C" int radhip_index_load_graph(radhip_index_t *idx, uint64_t n, int32_t 
         }
     }
     std::lock_guard<std::mutex> lk(idx->mu);
+    rh_layout_invalidate(idx);
     try {
         idx->h_levels.assign(levels, levels + n);
         idx->h_adj0.assign(adj0, adj0 + n * idx->cap0);
@@ -450,6 +481,7 @@ extern "C" int radhip_index_synth_graph(radhip_index_t *idx, uint64_t seed) {
     if (idx->n >= 0xFFFFFFFFull) RH_FAIL(RADHIP_E_INVALID, "n too large");
     std::lock_guard<std::mutex> lk(idx->mu);
     RH_TRY(rh_ensure_device(idx));
+    rh_layout_invalidate(idx);
     const uint64_t n = idx->n;
     const int32_t L = syn_max_level(n, idx->M);
     uint64_t nu = 0;
@@ -647,7 +679,9 @@ extern "C" int radhip_tanimoto_scan(radhip_index_t *idx, const uint8_t *queries,
     uint32_t *dpop = nullptr, *da = nullptr, *dorr = nullptr;
     const uint32_t pass = std::min<uint32_t>(nq, 8);
     int rc = RADHIP_OK;
-    auto cleanup = [&]() { if (dq) (void)hipFree(dq); if (dpop) (void)hipFree(dpop); if (da) (void)hipFree(da); if (dorr) (void)hipFree(dorr); };
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() { if (dq) (void)hipFree(dq); if (dpop) (void)hipFree(dpop); if (da) (void)hipFree(da); if (dorr) (void)hipFree(dorr);
+                           if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); };
 #define RH_G(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { radhip_set_error("%s failed: %s", #x, hipGetErrorString(e_)); cleanup(); return RADHIP_E_HIP; } } while (0)
     RH_G(hipMalloc((void **)&dq, padded.size()));
     RH_G(hipMalloc((void **)&dpop, (size_t)nq * 4));
@@ -655,9 +689,8 @@ extern "C" int radhip_tanimoto_scan(radhip_index_t *idx, const uint8_t *queries,
     RH_G(hipMalloc((void **)&dorr, (size_t)pass * count * 4));
     RH_G(hipMemcpyAsync(dq, padded.data(), padded.size(), hipMemcpyHostToDevice, idx->stream));
     RH_G(hipMemcpyAsync(dpop, pop.data(), (size_t)nq * 4, hipMemcpyHostToDevice, idx->stream));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
+    RH_G(hipEventCreate(&e0));
+    RH_G(hipEventCreate(&e1));
     g_last_kernel_ms = 0.0;
     for (uint32_t q0 = 0; q0 < nq && rc == RADHIP_OK; q0 += pass) {
         const int k = (int)std::min<uint32_t>(pass, nq - q0);
@@ -678,8 +711,6 @@ extern "C" int radhip_tanimoto_scan(radhip_index_t *idx, const uint8_t *queries,
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) g_last_kernel_ms += ms;
     }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
     cleanup();
     return rc;
 }
@@ -782,8 +813,10 @@ extern "C" int radhip_tanimoto_gather(radhip_index_t *idx, const uint8_t *querie
     stage_queries(idx, queries, nq, padded, pop);
     uint4 *dq = nullptr;
     uint32_t *dpop = nullptr, *dpq = nullptr, *dps = nullptr, *da = nullptr, *dorr = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() { if (dq) (void)hipFree(dq); if (dpop) (void)hipFree(dpop); if (dpq) (void)hipFree(dpq);
-                           if (dps) (void)hipFree(dps); if (da) (void)hipFree(da); if (dorr) (void)hipFree(dorr); };
+                           if (dps) (void)hipFree(dps); if (da) (void)hipFree(da); if (dorr) (void)hipFree(dorr);
+                           if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); };
     RH_G(hipMalloc((void **)&dq, padded.size()));
     RH_G(hipMalloc((void **)&dpop, (size_t)nq * 4));
     RH_G(hipMalloc((void **)&dpq, n_pairs * 4));
@@ -802,9 +835,8 @@ extern "C" int radhip_tanimoto_gather(radhip_index_t *idx, const uint8_t *querie
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, idx->device);
     uint32_t grid = (uint32_t)std::min<uint64_t>((n_pairs + per_block - 1) / per_block, (uint64_t)n_cu * RH_GATHER_BLOCKS_PER_CU);
     if (grid == 0) grid = 1;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
+    RH_G(hipEventCreate(&e0));
+    RH_G(hipEventCreate(&e1));
     (void)hipEventRecord(e0, idx->stream);
     switch (idx->lpr) {
         case 1: hipLaunchKernelGGL(gather_kernel<1>, dim3(grid), dim3(256), 0, idx->stream, idx->d_fp, dq, dpop, dpq, dps, n_pairs, da, dorr); break;
@@ -821,8 +853,6 @@ extern "C" int radhip_tanimoto_gather(radhip_index_t *idx, const uint8_t *querie
     {
         float ms = 0.f;
         g_last_kernel_ms = hipEventElapsedTime(&ms, e0, e1) == hipSuccess ? ms : 0.0;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
     }
     cleanup();
     return RADHIP_OK;

@@ -84,8 +84,7 @@ class Index:
         self._max_batch = int(max_batch)
         self._device = int(device)
         self._dev = DeviceIndex(self._ndim, self._M, self._cap0, self.expansion_add, device)
-        self._keys = np.empty(0, np.uint64)
-        self._key_to_slot = None
+        # the key <-> slot map lives in the library (radhip_index_set_keys / radhip_slots_from_keys)
         self._exclude_vectors = False
         if path is not None:
             self.load(path, exclude_vectors=exclude_vectors)
@@ -131,15 +130,18 @@ class Index:
     def memory_usage(self):
         inf = self._dev.info()
         n = inf.n
-        host = n * (1 + 4 + 4 * inf.connectivity_base) + inf.n_upper_rows * inf.connectivity * 4 + self._keys.nbytes
+        host = n * (1 + 4 + 4 * inf.connectivity_base) + inf.n_upper_rows * inf.connectivity * 4 + 8 * n
         return int(inf.device_bytes + host)
 
     @property
     def keys(self):
-        return self._keys
+        n = len(self)
+        out = np.empty(n, np.uint64)
+        check(_lib.lib().radhip_index_read_keys(self._dev._h, 0, n, ptr(out)))
+        return out
 
     def __len__(self):
-        return int(self._keys.shape[0])
+        return int(self._dev.info().n)     # the library's row count: never diverges from the device
 
     @property
     def levels_stats(self):
@@ -162,7 +164,14 @@ class Index:
         return self._dev
 
     def keys_of(self, slots) -> np.ndarray:
-        return self._keys[np.asarray(slots, dtype=np.int64)]
+        sl = np.ascontiguousarray(slots, dtype=np.uint32)
+        out = np.empty(sl.shape, np.uint64)
+        check(_lib.lib().radhip_keys_from_slots(self._dev._h, ptr(sl), sl.size, ptr(out)))
+        return out
+
+    def _set_keys(self, first: int, keys: np.ndarray) -> None:
+        keys = np.ascontiguousarray(keys, np.uint64)
+        check(_lib.lib().radhip_index_set_keys(self._dev._h, first, ptr(keys), keys.shape[0]))
 
     # ------------------------------------------------------------ build
     def add(self, keys, vectors, log: bool = False, threads: int = 0, copy: bool = True, **kwargs):
@@ -177,9 +186,9 @@ class Index:
             raise ValueError(f"{keys.shape[0]} keys for {n} vectors")
         if self._exclude_vectors:
             raise RuntimeError("index was loaded with exclude_vectors=True; it cannot be extended")
+        first = len(self)
         check(_lib.lib().radhip_index_add(self._dev._h, ptr(vectors), n, self._seed, self._max_batch))
-        self._keys = np.concatenate([self._keys, keys])
-        self._key_to_slot = None
+        self._set_keys(first, keys)
         return keys
 
     def search(self, vectors, count: int = 10, expansion: Optional[int] = None, exact: bool = False, **kwargs) -> Matches:
@@ -203,7 +212,10 @@ class Index:
                 aa = np.take_along_axis(a, order, 1)
                 oo = np.take_along_axis(o, order, 1)
                 counts = np.full(nq, k, np.uint32)
-            return Matches(self._keys[slots.astype(np.int64)], distance_f32(aa, oo), counts, slots)
+            keys = np.zeros(slots.shape, np.uint64)
+            ok = slots != NO_SLOT
+            keys[ok] = self.keys_of(slots[ok])
+            return Matches(keys, distance_f32(aa, oo), counts, slots)
         ef = max(int(expansion or self.expansion_search), k)
         slots = np.full((nq, k), NO_SLOT, np.uint32)
         a = np.zeros((nq, k), np.uint32)
@@ -215,30 +227,35 @@ class Index:
                                        ptr(counts), ptr(ev), ptr(pp)))
         keys = np.zeros((nq, k), np.uint64)
         valid = np.arange(k)[None, :] < counts[:, None]      # rows are padded with NO_SLOT past counts
-        keys[valid] = self._keys[slots[valid].astype(np.int64)]
+        keys[valid] = self.keys_of(slots[valid])
         return Matches(keys, distance_f32(a, o), counts, slots, int(pp.sum()), int(ev.sum()))
 
     # ------------------------------------------------------------ adjacency reads (RAD's hot calls)
     def get_neighbors(self, node_id: int, level: int) -> np.ndarray:
         """Flat [neighbor_slot, neighbor_key, ...] of one node on one level; raises if the node
         does not exist on that level."""
-        slots = self._dev.get_neighbors(int(node_id), int(level))
-        out = np.empty(2 * slots.shape[0], np.uint64)
-        out[0::2] = slots
-        out[1::2] = self._keys[slots.astype(np.int64)]
-        return out
+        out = np.empty(128, np.uint64)
+        n = C.c_uint32(0)
+        check(_lib.lib().radhip_get_neighbors_keyed(self._dev._h, int(node_id), int(level), ptr(out), 64, C.byref(n)))
+        return out[: 2 * n.value].copy()
 
     def get_top_level_nodes(self) -> np.ndarray:
         slots = self._dev.get_top_level_nodes()
         out = np.empty(2 * slots.shape[0], np.uint64)
         out[0::2] = slots
-        out[1::2] = self._keys[slots.astype(np.int64)]
+        out[1::2] = self.keys_of(slots)
         return out
 
     def get_node_ids_from_keys(self, keys) -> np.ndarray:
-        if self._key_to_slot is None:
-            self._key_to_slot = {int(k): i for i, k in enumerate(self._keys)}
-        return np.array([self._key_to_slot[int(k)] for k in np.atleast_1d(keys)], dtype=np.uint64)
+        """key -> slot (radhip_slots_from_keys: binary search in the library, no Python dict);
+        an unknown key raises KeyError, as a dict lookup would."""
+        k = np.ascontiguousarray(np.atleast_1d(keys), dtype=np.uint64)
+        out = np.empty(k.shape[0], np.uint32)
+        missing = C.c_uint64(0)
+        check(_lib.lib().radhip_slots_from_keys(self._dev._h, ptr(k), k.shape[0], ptr(out), C.byref(missing)))
+        if missing.value:
+            raise KeyError(int(k[out == NO_SLOT][0]))
+        return out.astype(np.uint64)
 
     # ------------------------------------------------------------ external graphs
     def load_graph(self, keys, vectors, levels, adj0, upper_row, adjU, max_level: int, entry: int):
@@ -248,8 +265,7 @@ class Index:
         if vectors is not None:
             self._dev.load_vectors(vectors)
         self._dev.load_graph(levels, adj0, upper_row, adjU, max_level, entry)
-        self._keys = keys
-        self._key_to_slot = None
+        self._set_keys(0, keys)
         self._exclude_vectors = vectors is None
 
     # ------------------------------------------------------------ persistence
@@ -267,7 +283,7 @@ class Index:
             np.savez(f, format=np.bytes_(b"rad_amd.index.v1"), ndim=self._ndim, connectivity=self._M,
                      connectivity_base=self._cap0, expansion_add=self.expansion_add,
                      expansion_search=self.expansion_search, seed=self._seed, max_level=inf.max_level,
-                     entry=inf.entry, keys=self._keys, levels=levels, adj0=adj0, upper_row=upper_row,
+                     entry=inf.entry, keys=self.keys, levels=levels, adj0=adj0, upper_row=upper_row,
                      adjU=adjU, vectors=vec)
 
     def load(self, path: str, exclude_vectors: bool = False) -> None:

@@ -93,6 +93,7 @@ SIGNATURES = {
     "radhip_traversal_resident_capacity": (C.c_int, [_P, C.POINTER(_U32)]),
     "radhip_traversal_state_bytes": (_U64, [_P]),
     "radhip_traversal_kernel": (C.c_int, [_P]),
+    "radhip_traversal_table": (C.c_int, [_P]),
     "radhip_traversal_set_targets": (C.c_int, [_P, _P]),
     "radhip_traversal_frontier": (C.c_int, [_P, _P, _P]),
     "radhip_comm_unique_id": (C.c_int, [_P]),

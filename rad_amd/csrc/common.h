@@ -90,6 +90,7 @@ struct radhip_index {
 };
 
 void rh_layout_invalidate(radhip_index *idx);      // layout.hip: the graph changed
+int rh_optimize_layout_locked(radhip_index *idx, uint32_t n_threads);   // idx->mu held by the caller
 
 int rh_ensure_device(radhip_index *idx);           // lazy HIP init + pending uploads
 int rh_ensure_host_graph(radhip_index *idx);       // D2H mirror of a device-generated graph

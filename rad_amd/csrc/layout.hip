@@ -224,6 +224,10 @@ static void layout_quality(radhip_index *idx) {
 extern "C" int radhip_index_optimize_layout(radhip_index_t *idx, uint32_t n_threads) {
     if (!idx) RH_FAIL(RADHIP_E_INVALID, "null index");
     std::lock_guard<std::mutex> lk(idx->mu);
+    return rh_optimize_layout_locked(idx, n_threads);
+}
+
+int rh_optimize_layout_locked(radhip_index *idx, uint32_t n_threads) {
     if (!idx->has_graph || idx->g_n == 0) RH_FAIL(RADHIP_E_STATE, "no graph loaded");
     RH_TRY(rh_ensure_host_graph(idx));
     const uint64_t n = idx->g_n;

@@ -70,9 +70,13 @@ struct TravHeader {
     uint64_t pivot;
     uint64_t n_repivot, n_flush;
     uint32_t stg_cnt, n_runs, qpop, primed;
-    uint32_t dq, pad0;
+    uint32_t dq, mid_pos;
     int32_t status;
-    uint32_t pad;
+    uint32_t dm;
+    // trav4_kernel's three-level queue: keys below mid_limit are in registers / staging / the mid run
+    // [mid_pos, mid_end) of the key pool; the far runs hold keys >= mid_limit only
+    uint64_t mid_limit, far_min;
+    uint32_t mid_end, pad;
 };
 
 struct TravParams {
@@ -90,6 +94,12 @@ struct TravParams {
     uint32_t ht_log2;
     unsigned long long *ut;
     uint32_t ut_log2;
+    // grouped visited/scored table (GT kernels; needs the index's graph-locality layout, layout.hip):
+    // per traversal 2^gt_log2 lines of 8 chunks {tag, 48 seen bits, 48 pend bits}, see traverse4.inc
+    const uint2 *adjx0, *adjxU, *topx;   // {slot, layout id} pair rows
+    const uint32_t *lid;
+    unsigned long long *gt;              // [nq << (gt_log2 + 4)] (two u64 per chunk)
+    uint32_t gt_log2;
     uint2 *scored;
     uint64_t scored_cap;
     unsigned long long *pq;
@@ -98,6 +108,7 @@ struct TravParams {
     unsigned long long *r_save;    // [nq * RK * 64] near keys
     uint2 *runs;                   // [nq * MAX_RUNS] {pos, end}
     unsigned long long *rhead;     // [nq * MAX_RUNS] head key of every run (INF = exhausted)
+    unsigned long long *midpool;   // trav4_kernel: [nq * 256] the sorted mid run of every traversal
     uint32_t *poplog_nodes;
     uint8_t *poplog_levels;
     uint64_t poplog_cap;
@@ -651,6 +662,11 @@ struct radhip_traversal {
            rhead_bytes = 0, rsave_bytes = 0, hdr_bytes = 0, log_bytes = 0;
     bool fresh_tables = true;   // tables not cleared yet (first upload)
     bool use4 = false;   // trav4_kernel (four traversals per wave) when every adjacency row is <= 16 wide
+    bool use_gt = false; // grouped visited/scored table (needs the index's graph-locality layout)
+    size_t gt_bytes = 0;
+    uint64_t graph_gen = 0;   // generation of the index this state was sized for
+    std::vector<uint8_t> h_queries;   // host copy: the grouped table's overflow fallback re-arms the batch itself
+    uint32_t ht_log2 = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0.0;
     uint64_t launches = 0;
@@ -665,6 +681,10 @@ static uint32_t log2_ceil(uint64_t x) {
 
 static int trav_upload_queries(radhip_traversal *t, const uint8_t *queries) {
     radhip_index *idx = t->idx;
+    if (t->use_gt && queries != t->h_queries.data()) {
+        try { t->h_queries.assign(queries, queries + (size_t)t->nq * idx->row_bytes); }
+        catch (...) { RH_FAIL(RADHIP_E_NOMEM, "out of host memory"); }
+    }
     std::vector<uint8_t> padded((size_t)t->nq * idx->row_stride, 0);
     std::vector<TravHeader> hdr(t->nq);
     memset(hdr.data(), 0, hdr.size() * sizeof(TravHeader));
@@ -677,17 +697,17 @@ static int trav_upload_queries(radhip_traversal *t, const uint8_t *queries) {
         hdr[i].frontier_key = RH_KEY_INF;
         hdr[i].pivot = RH_KEY_INF;
         hdr[i].dq = DQ_INIT;
+        hdr[i].mid_limit = RH_KEY_INF;
+        hdr[i].far_min = RH_KEY_INF;
+        hdr[i].dm = 1u << 12;
     }
     RH_HIP(hipMemcpyAsync(t->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, idx->stream));
     RH_HIP(hipMemcpyAsync(t->P.hdr, hdr.data(), t->hdr_bytes, hipMemcpyHostToDevice, idx->stream));
-    if (t->fresh_tables) {
+    if (t->fresh_tables || ++t->P.epoch >= EPOCH_LIMIT) {   // first use, or epoch space exhausted: really clear
         t->P.epoch = 0;
         t->fresh_tables = false;
-        RH_HIP(hipMemsetAsync(t->P.ht, 0xFF, t->ht_bytes, idx->stream));
-        RH_HIP(hipMemsetAsync(t->P.ut, 0x00, t->ut_bytes, idx->stream));
-    } else if (++t->P.epoch >= EPOCH_LIMIT) {   // epoch space exhausted: really clear
-        t->P.epoch = 0;
-        RH_HIP(hipMemsetAsync(t->P.ht, 0xFF, t->ht_bytes, idx->stream));
+        if (t->P.ht) RH_HIP(hipMemsetAsync(t->P.ht, 0xFF, t->ht_bytes, idx->stream));
+        if (t->P.gt) RH_HIP(hipMemsetAsync(t->P.gt, 0xFF, t->gt_bytes, idx->stream));
         RH_HIP(hipMemsetAsync(t->P.ut, 0x00, t->ut_bytes, idx->stream));
     }
     RH_HIP(hipStreamSynchronize(idx->stream));
@@ -702,12 +722,14 @@ extern "C" int radhip_traversal_destroy(radhip_traversal_t *t) {
     if (t->d_queries) (void)hipFree(t->d_queries);
     if (t->P.hdr) (void)hipFree(t->P.hdr);
     if (t->P.ht) (void)hipFree(t->P.ht);
+    if (t->P.gt) (void)hipFree(t->P.gt);
     if (t->P.ut) (void)hipFree(t->P.ut);
     if (t->P.scored) (void)hipFree(t->P.scored);
     if (t->P.pq) (void)hipFree(t->P.pq);
     if (t->P.stg_save) (void)hipFree(t->P.stg_save);
     if (t->P.runs) (void)hipFree(t->P.runs);
     if (t->P.rhead) (void)hipFree(t->P.rhead);
+    if (t->P.midpool) (void)hipFree(t->P.midpool);
     if (t->P.r_save) (void)hipFree(t->P.r_save);
     if (t->P.poplog_nodes) (void)hipFree(t->P.poplog_nodes);
     if (t->P.poplog_levels) (void)hipFree(t->P.poplog_levels);
@@ -732,6 +754,11 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     if (idx->g_n > 1000000000ull) RH_FAIL(RADHIP_E_INVALID, "RAD traversal needs slots < 1e9");
     std::lock_guard<std::mutex> lk(idx->mu);
     RH_TRY(rh_ensure_device(idx));
+    {   // RADHIP_TABLE=group on an index without a layout: compute one first (how the parity suites cover
+        // the grouped table on every graph they build)
+        const char *e = getenv("RADHIP_TABLE");
+        if (e && e[0] == 'g' && !idx->layout_valid) RH_TRY(rh_optimize_layout_locked(idx, 0));
+    }
     radhip_traversal *t = new (std::nothrow) radhip_traversal();
     if (!t) RH_FAIL(RADHIP_E_NOMEM, "out of host memory");
     t->idx = idx; t->nq = nq; t->n_to_score = n_to_score; t->flags = flags;
@@ -755,6 +782,8 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     uint64_t ut_need = std::min<uint64_t>(2 * up_pairs + 64, scored_cap * 8 / idx->M + 1024);
     const uint32_t ut_log2 = std::max<uint32_t>(10, log2_ceil(ut_need));
     if (ht_log2 > 31 || ut_log2 > 31) { delete t; RH_FAIL(RADHIP_E_INVALID, "n_to_score too large"); }
+    // every live queue key fits: a scored node is in the queue once per level at most; trav4_kernel collects
+    // the garbage (consumed run prefixes) when the pool fills up
     const uint64_t pq_cap = scored_cap + ((uint64_t)1 << ut_log2);
     if (pq_cap >= 0xFFFFFFFFull) { delete t; RH_FAIL(RADHIP_E_INVALID, "n_to_score too large"); }
     TravParams &P = t->P;
@@ -774,8 +803,23 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
         if (getenv("RADHIP_SPEC") && getenv("RADHIP_SPEC")[0] == '0') P.spec_passes = 0u;
     }
     P.ht_log2 = ht_log2; P.ut_log2 = ut_log2; P.scored_cap = scored_cap; P.pq_cap = pq_cap;
+    t->ht_log2 = ht_log2;
+    t->graph_gen = idx->graph_gen;
+    {   // Grouped table: when the index carries a graph-locality layout whose rows span clearly fewer groups
+        // than they have neighbours (RADHIP_TABLE=group|hash forces one).  8 chunks per line, one chunk per
+        // scored node in the worst case, at most 80 % of the chunk slots used.
+        const char *e = getenv("RADHIP_TABLE");
+        const bool force_hash = e && e[0] == 'h', force_group = e && e[0] == 'g';
+        const uint32_t gt_log2 = std::max<uint32_t>(7, log2_ceil((scored_cap * 5 + 31) / 32));
+        const bool can = idx->layout_valid && idx->d_adjx0 && t->use4 && gt_log2 <= 17;
+        const bool pays = idx->layout_lines_per_row <= 0.75 * idx->layout_degree;
+        t->use_gt = can && !force_hash && (pays || force_group);
+        P.gt_log2 = gt_log2;
+        P.adjx0 = idx->d_adjx0; P.adjxU = idx->d_adjxU; P.topx = idx->d_topx; P.lid = idx->d_lid;
+    }
     t->hdr_bytes = (size_t)nq * sizeof(TravHeader);
-    t->ht_bytes = ((size_t)nq << ht_log2) * 8;
+    t->gt_bytes = t->use_gt ? ((size_t)nq << (P.gt_log2 + 4)) * 8 : 0;
+    t->ht_bytes = t->use_gt ? 0 : ((size_t)nq << ht_log2) * 8;
     t->ut_bytes = ((size_t)nq << ut_log2) * 8;
     t->scored_bytes = (size_t)nq * scored_cap * sizeof(uint2);
     t->pq_bytes = (size_t)nq * pq_cap * 8;
@@ -794,13 +838,15 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     } while (0)
     RH_A(t->d_queries, (size_t)nq * idx->row_stride);
     if (rc == 0) RH_A(P.hdr, t->hdr_bytes);
-    if (rc == 0) RH_A(P.ht, t->ht_bytes);
+    if (rc == 0 && t->ht_bytes) RH_A(P.ht, t->ht_bytes);
+    if (rc == 0 && t->gt_bytes) RH_A(P.gt, t->gt_bytes);
     if (rc == 0) RH_A(P.ut, t->ut_bytes);
     if (rc == 0) RH_A(P.scored, t->scored_bytes);
     if (rc == 0) RH_A(P.pq, t->pq_bytes);
     if (rc == 0) RH_A(P.stg_save, t->stg_bytes);
     if (rc == 0) RH_A(P.runs, t->runs_bytes);
     if (rc == 0) RH_A(P.rhead, t->rhead_bytes);
+    if (rc == 0) RH_A(P.midpool, (size_t)nq * 256 * 8);
     if (rc == 0) RH_A(P.r_save, t->rsave_bytes);
     if (rc == 0 && (flags & RADHIP_TRAV_LOG_POPS)) {
         P.poplog_cap = pq_cap;
@@ -821,19 +867,15 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
 extern "C" int radhip_traversal_reset(radhip_traversal_t *t, const uint8_t *queries) {
     if (!t || !queries) RH_FAIL(RADHIP_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(t->idx->mu);
+    if (t->graph_gen != t->idx->graph_gen)
+        RH_FAIL(RADHIP_E_STATE, "the index changed since this traversal object was created: create a new one");
     RH_HIP(hipSetDevice(t->idx->device));
     return trav_upload_queries(t, queries);
 }
 
-extern "C" int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, uint32_t *out_running) {
-    if (!t) RH_FAIL(RADHIP_E_INVALID, "null traversal");
+// one launch of the kernel the object is bound to, to completion of the stream; kernel time accumulated
+static int trav_launch(radhip_traversal *t) {
     radhip_index *idx = t->idx;
-    std::lock_guard<std::mutex> lk(idx->mu);
-    RH_HIP(hipSetDevice(idx->device));
-    // the graph may have been re-uploaded since create
-    t->P.fp = idx->d_fp; t->P.adj0 = idx->d_adj0; t->P.upper_row = idx->d_upper_row;
-    t->P.adjU = idx->d_adjU; t->P.top = idx->d_top;
-    t->P.max_pops = max_pops;
 #ifdef RH_PROFILE
     static unsigned long long *d_prof = nullptr;
     if (!d_prof) { (void)hipMalloc((void **)&d_prof, 80); }
@@ -843,24 +885,24 @@ extern "C" int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, ui
     t->P.prof = nullptr;
 #endif
     RH_HIP(hipEventRecord(t->ev0, idx->stream));
-    if (t->use4) {
-        const uint32_t grid = (t->nq + 3u) / 4u;
-        switch (idx->lpr) {
-            case 1: hipLaunchKernelGGL(trav4_kernel<1>, dim3(grid), dim3(64), 0, idx->stream, t->P); break;
-            case 2: hipLaunchKernelGGL(trav4_kernel<2>, dim3(grid), dim3(64), 0, idx->stream, t->P); break;
-            case 4: hipLaunchKernelGGL(trav4_kernel<4>, dim3(grid), dim3(64), 0, idx->stream, t->P); break;
-            case 8: hipLaunchKernelGGL(trav4_kernel<8>, dim3(grid), dim3(64), 0, idx->stream, t->P); break;
-            default: hipLaunchKernelGGL(trav4_kernel<16>, dim3(grid), dim3(64), 0, idx->stream, t->P); break;
-        }
-    } else {
-        switch (idx->lpr) {
-            case 1: hipLaunchKernelGGL(trav_kernel<1>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
-            case 2: hipLaunchKernelGGL(trav_kernel<2>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
-            case 4: hipLaunchKernelGGL(trav_kernel<4>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
-            case 8: hipLaunchKernelGGL(trav_kernel<8>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
-            default: hipLaunchKernelGGL(trav_kernel<16>, dim3(t->nq), dim3(64), 0, idx->stream, t->P); break;
-        }
+#define RH_TRAV_CASES(KERNEL, GRID)                                                                              \
+    switch (idx->lpr) {                                                                                          \
+        case 1: hipLaunchKernelGGL((KERNEL(1)), dim3(GRID), dim3(64), 0, idx->stream, t->P); break;              \
+        case 2: hipLaunchKernelGGL((KERNEL(2)), dim3(GRID), dim3(64), 0, idx->stream, t->P); break;              \
+        case 4: hipLaunchKernelGGL((KERNEL(4)), dim3(GRID), dim3(64), 0, idx->stream, t->P); break;              \
+        case 8: hipLaunchKernelGGL((KERNEL(8)), dim3(GRID), dim3(64), 0, idx->stream, t->P); break;              \
+        default: hipLaunchKernelGGL((KERNEL(16)), dim3(GRID), dim3(64), 0, idx->stream, t->P); break;            \
     }
+#define RH_K4G(LPR) trav4_kernel<LPR, true>
+#define RH_K4H(LPR) trav4_kernel<LPR, false>
+#define RH_K1H(LPR) trav_kernel<LPR>
+    if (t->use4 && t->use_gt) { RH_TRAV_CASES(RH_K4G, (t->nq + 3u) / 4u) }
+    else if (t->use4) { RH_TRAV_CASES(RH_K4H, (t->nq + 3u) / 4u) }
+    else { RH_TRAV_CASES(RH_K1H, t->nq) }
+#undef RH_K4G
+#undef RH_K4H
+#undef RH_K1H
+#undef RH_TRAV_CASES
     RH_HIP(hipGetLastError());
     RH_HIP(hipEventRecord(t->ev1, idx->stream));
     RH_HIP(hipStreamSynchronize(idx->stream));
@@ -879,17 +921,60 @@ extern "C" int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, ui
 #endif
     t->kernel_ms += ms;
     t->launches++;
-    std::vector<TravHeader> hdr(t->nq);
-    RH_HIP(hipMemcpy(hdr.data(), t->P.hdr, t->hdr_bytes, hipMemcpyDeviceToHost));
-    uint32_t running = 0;
-    int bad = 0;
-    for (uint32_t i = 0; i < t->nq; ++i) {
-        if (hdr[i].status == 0) running++;  // status 3 (intermediate target reached) is parked, not running
-        if (hdr[i].status < 0 && !bad) bad = hdr[i].status;
-    }
-    if (out_running) *out_running = running;
-    if (bad) RH_FAIL(bad, "traversal state overflowed a fixed-capacity device structure (status %d)", bad);
     return RADHIP_OK;
+}
+
+// The grouped table filled one of its chunk positions (layout ids that pile onto one position: possible
+// only for an adversarial layout).  The batch has not returned anything yet: re-arm it with the per-slot
+// hash table, which has no such limit below its sized capacity, and run it again from the start.
+static int trav_fall_back_to_hash(radhip_traversal *t) {
+    radhip_index *idx = t->idx;
+    if (t->P.gt) { (void)hipFree(t->P.gt); t->P.gt = nullptr; t->state_bytes -= t->gt_bytes; t->gt_bytes = 0; }
+    t->use_gt = false;
+    t->P.ht_log2 = t->ht_log2;
+    t->ht_bytes = ((size_t)t->nq << t->ht_log2) * 8;
+    hipError_t e = hipMalloc((void **)&t->P.ht, t->ht_bytes);
+    if (e != hipSuccess) RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP,
+                                 "hipMalloc(%zu) for the hash-table fallback failed: %s", t->ht_bytes, hipGetErrorString(e));
+    t->state_bytes += t->ht_bytes;
+    t->fresh_tables = true;
+    const double ms = t->kernel_ms;
+    const uint64_t launches = t->launches;
+    RH_TRY(trav_upload_queries(t, t->h_queries.data()));
+    t->kernel_ms = ms; t->launches = launches;   // the aborted launch stays on the clock
+    (void)idx;
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, uint32_t *out_running) {
+    if (!t) RH_FAIL(RADHIP_E_INVALID, "null traversal");
+    radhip_index *idx = t->idx;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_HIP(hipSetDevice(idx->device));
+    // n_top, start_level, the table sizes and the layout were taken from the graph at create time: a
+    // traversal object does not survive an add() / load_graph() (the kernel would read freed arrays)
+    if (t->graph_gen != idx->graph_gen)
+        RH_FAIL(RADHIP_E_STATE, "the index changed since this traversal object was created: create a new one");
+    t->P.max_pops = max_pops;
+    const bool first_launch = t->launches == 0;
+    std::vector<TravHeader> hdr(t->nq);
+    for (int attempt = 0;; ++attempt) {
+        RH_TRY(trav_launch(t));
+        RH_HIP(hipMemcpy(hdr.data(), t->P.hdr, t->hdr_bytes, hipMemcpyDeviceToHost));
+        uint32_t running = 0;
+        int bad = 0;
+        for (uint32_t i = 0; i < t->nq; ++i) {
+            if (hdr[i].status == 0) running++;  // status 3 (intermediate target reached) is parked, not running
+            if (hdr[i].status < 0 && !bad) bad = hdr[i].status;
+        }
+        if (bad == RADHIP_E_CAPACITY && t->use_gt && first_launch && attempt == 0) {
+            RH_TRY(trav_fall_back_to_hash(t));
+            continue;
+        }
+        if (out_running) *out_running = running;
+        if (bad) RH_FAIL(bad, "traversal state overflowed a fixed-capacity device structure (status %d)", bad);
+        return RADHIP_OK;
+    }
 }
 
 extern "C" int radhip_traversal_stats(const radhip_traversal_t *t, radhip_trav_stats_t *out) {
@@ -1041,11 +1126,11 @@ static int trav_capacity_of(radhip_index *idx, bool use4, uint32_t *out) {
     hipError_t e;
     if (use4) {
         switch (idx->lpr) {
-            case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<1>, 64, 0); break;
-            case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<2>, 64, 0); break;
-            case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<4>, 64, 0); break;
-            case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<8>, 64, 0); break;
-            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<16>, 64, 0); break;
+            case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<1, false>, 64, 0); break;
+            case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<2, false>, 64, 0); break;
+            case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<4, false>, 64, 0); break;
+            case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<8, false>, 64, 0); break;
+            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<16, false>, 64, 0); break;
         }
     } else
     switch (idx->lpr) {
@@ -1077,4 +1162,6 @@ extern "C" int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t 
 
 // 4 = trav4_kernel (four traversals per wavefront), 1 = trav_kernel
 extern "C" int radhip_traversal_kernel(const radhip_traversal_t *t) { return t ? (t->use4 ? 4 : 1) : 0; }
+// 1 = grouped visited/scored table (2 bits per node, keyed by the graph-locality layout), 0 = per-slot hash table
+extern "C" int radhip_traversal_table(const radhip_traversal_t *t) { return t ? (t->use_gt ? 1 : 0) : -1; }
 

@@ -106,6 +106,26 @@ class DeviceIndex:
         check(self._L.radhip_get_top_level_nodes(self._h, ptr(out), n.value, C.byref(n)))
         return out
 
+    def optimize_layout(self, n_threads: int = 0) -> "_lib.LayoutInfo":
+        """Compute the graph-locality layout the grouped visited table is keyed by (performance only:
+        no result depends on it).  Returns its statistics."""
+        check(self._L.radhip_index_optimize_layout(self._h, n_threads))
+        return self.layout_info()
+
+    def layout_info(self) -> "_lib.LayoutInfo":
+        out = _lib.LayoutInfo()
+        check(self._L.radhip_index_layout_info(self._h, C.byref(out)))
+        return out
+
+    def set_layout(self, lid: np.ndarray) -> None:
+        lid = np.ascontiguousarray(lid, np.uint32)
+        check(self._L.radhip_index_set_layout(self._h, ptr(lid)))
+
+    def read_layout(self) -> np.ndarray:
+        out = np.empty(self.info().n, np.uint32)
+        check(self._L.radhip_index_read_layout(self._h, ptr(out)))
+        return out
+
     def traversal_capacity(self) -> int:
         """Traversals resident on the device at once (one wavefront each)."""
         n = C.c_uint32(0)
@@ -260,6 +280,11 @@ class DeviceTraversal:
 
     def state_bytes(self) -> int:
         return int(self._L.radhip_traversal_state_bytes(self._h))
+
+    @property
+    def table(self) -> str:
+        """'grouped' (2 bits per node, keyed by the index's graph-locality layout) or 'hash' (one entry per node)."""
+        return "grouped" if int(self._L.radhip_traversal_table(self._h)) == 1 else "hash"
 
     @property
     def kernel(self) -> str:

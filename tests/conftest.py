@@ -31,14 +31,20 @@ def gpu():
 
 
 def pytest_generate_tests(metafunc):
-    # traversal tests that do not name a kernel run twice: with the library's own choice ("auto":
-    # small batches go to the one-per-wavefront kernel) and with the four-per-wavefront kernel forced
+    # traversal tests that do not name a kernel run three times: with the library's own choice ("auto":
+    # small batches go to the one-per-wavefront kernel), with the four-per-wavefront kernel forced, and
+    # with that kernel on the grouped visited table (the library computes a graph-locality layout for
+    # whatever graph the test installed); kernels that have no grouped variant keep the hash table
     if "trav_mode" in metafunc.fixturenames:
-        metafunc.parametrize("trav_mode", ["auto", "trav4"], indirect=True)
+        metafunc.parametrize("trav_mode", ["auto", "trav4", "trav4-grouped"], indirect=True)
 
 
 @pytest.fixture
 def trav_mode(request, monkeypatch):
-    if request.param == "trav4":
+    if request.param in ("trav4", "trav4-grouped"):
         monkeypatch.setenv("RADHIP_TRAV", "4")
+    if request.param == "trav4-grouped":
+        monkeypatch.setenv("RADHIP_TABLE", "group")
+    else:
+        monkeypatch.delenv("RADHIP_TABLE", raising=False)
     return request.param

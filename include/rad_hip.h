@@ -226,7 +226,7 @@ typedef struct {
     int32_t status;      /* 0 running, 1 done(n_to_score), 2 done(queue empty),
                             3 parked at an intermediate target,
                             negative RADHIP_E_* on a device-side failure       */
-    int32_t reserved;
+    int32_t n_remid;     /* queue maintenance: mid-level refills (the only pass over every far run) */
 } radhip_trav_stats_t;
 
 #define RADHIP_TRAV_LOG_POPS 1u  /* keep the (node, level) expansion log      */

@@ -334,6 +334,139 @@ done:
 #undef SCORE_NODE
 }
 
+/* ====================================================================== */
+/* the same traversal as a resumable stepper: scores come from outside    */
+/* ====================================================================== */
+/* What the row-sharded multi-GPU mode needs: the control flow of orc_rad_traverse cut at the point
+ * where a fingerprint is read.  One step = apply the scores of the pending requests (scored insert +
+ * queue insert, rad/coordination_service.py:379-389), then prime the next batch of top-level nodes or
+ * pop / expand until some neighbour needs a score (rad/distributed_worker.py:296-305: only nodes not
+ * yet in the scored set are scored) or the traversal ends.  The stepper never touches the corpus: the
+ * caller evaluates the requested slots wherever their rows live.  Driven with a local evaluator it
+ * reproduces orc_rad_traverse exactly (tests/test_oracle_golden.py). */
+struct orc_stepper {
+    const orc_graph_t *g;
+    uint64_t n_to_score;
+    pq_t pq;
+    hset_t visited, scored;
+    uint32_t *out_slots, *out_and, *out_or;
+    uint64_t out_cap, n_scored, n_pops, n_nbr;
+    uint32_t *pop_nodes; uint8_t *pop_levels; uint64_t pop_cap;
+    uint32_t *top; uint64_t n_top, prime_at;
+    int start_level;
+    uint32_t pend[64]; uint32_t n_pend; int pend_level; int pend_prime;
+    int status;   /* 0 running, 1 done (n_to_score), 2 done (queue empty), <0 error */
+};
+
+orc_stepper_t *orc_stepper_create(const orc_graph_t *g, uint64_t n_to_score, uint64_t pop_cap) {
+    orc_stepper_t *s = (orc_stepper_t *)calloc(1, sizeof *s);
+    s->g = g; s->n_to_score = n_to_score;
+    hset_init(&s->visited, n_to_score + 64, 0);
+    hset_init(&s->scored, n_to_score + 64, 1);
+    s->n_top = 0;
+    for (uint64_t i = 0; i < g->n; ++i) if (g->levels[i] == g->max_level) s->n_top++;
+    s->top = (uint32_t *)malloc((s->n_top ? s->n_top : 1) * 4);
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < g->n; ++i) if (g->levels[i] == g->max_level) s->top[k++] = (uint32_t)i;
+    s->out_cap = n_to_score + 64 + s->n_top;
+    s->out_slots = (uint32_t *)malloc(s->out_cap * 4);
+    s->out_and = (uint32_t *)malloc(s->out_cap * 4);
+    s->out_or = (uint32_t *)malloc(s->out_cap * 4);
+    s->pop_cap = pop_cap;
+    s->pop_nodes = pop_cap ? (uint32_t *)malloc(pop_cap * 4) : NULL;
+    s->pop_levels = pop_cap ? (uint8_t *)malloc(pop_cap) : NULL;
+    s->start_level = g->max_level > 0 ? g->max_level - 1 : 0;
+    return s;
+}
+
+void orc_stepper_destroy(orc_stepper_t *s) {
+    if (!s) return;
+    free(s->pq.v); hset_free(&s->visited); hset_free(&s->scored);
+    free(s->out_slots); free(s->out_and); free(s->out_or); free(s->pop_nodes); free(s->pop_levels); free(s->top);
+    free(s);
+}
+
+static void stepper_push(orc_stepper_t *s, uint32_t slot, uint32_t a, uint32_t o, int level) {
+    pq_item_t it = {orc_distance_f32(a, o), slot, a, o, (uint8_t)level};
+    pq_push(&s->pq, it);
+}
+
+/* and_in/or_in: counts of the slots returned by the previous call, same order.  Returns the number of
+ * slots written to req_out (their scores are due at the next call), 0 when the traversal has ended. */
+int orc_stepper_step(orc_stepper_t *s, const uint32_t *and_in, const uint32_t *or_in, uint32_t *req_out,
+                     uint32_t req_cap) {
+    if (s->status != 0) return 0;
+    /* ---- finish: the pending nodes are scored now */
+    for (uint32_t i = 0; i < s->n_pend; ++i) {
+        if (s->n_scored >= s->out_cap) { s->status = -2; return 0; }
+        const uint32_t slot = s->pend[i];
+        s->out_slots[s->n_scored] = slot; s->out_and[s->n_scored] = and_in[i]; s->out_or[s->n_scored] = or_in[i];
+        hset_test_and_set(&s->scored, slot, (uint32_t)s->n_scored, NULL);
+        s->n_scored++;
+        stepper_push(s, slot, and_in[i], or_in[i], s->pend_level);
+    }
+    s->n_pend = 0;
+    if (req_cap > 64) req_cap = 64;
+    /* ---- prime: rad/traverser.py:141-170, req_cap top-level nodes at a time */
+    if (s->prime_at < s->n_top) {
+        while (s->prime_at < s->n_top && s->n_pend < req_cap) {
+            const uint32_t slot = s->top[s->prime_at++];
+            hset_test_and_set(&s->visited, ((uint64_t)slot << 8) | (uint64_t)s->start_level, 0, NULL);
+            s->pend[s->n_pend++] = slot;      /* top-level nodes are distinct and nothing is scored yet */
+        }
+        s->pend_level = s->start_level;
+        memcpy(req_out, s->pend, s->n_pend * 4);
+        return (int)s->n_pend;
+    }
+    /* ---- pop / expand until a neighbour needs a score */
+    for (;;) {
+        if (s->n_scored >= s->n_to_score) { s->status = 1; return 0; }
+        pq_item_t cur;
+        if (!pq_pop(&s->pq, &cur)) { s->status = 2; return 0; }
+        if (s->pop_nodes && s->n_pops < s->pop_cap) { s->pop_nodes[s->n_pops] = cur.slot; s->pop_levels[s->n_pops] = cur.level; }
+        s->n_pops++;
+        uint32_t cap = 0;
+        const uint32_t *row = graph_row(s->g, cur.slot, cur.level, &cap);
+        if (!row) { s->status = -3; return 0; }
+        for (uint32_t j = 0; j < cap && row[j] != ORC_NO_SLOT; ++j) {
+            const uint32_t nb = row[j];
+            s->n_nbr++;
+            if (hset_test_and_set(&s->visited, ((uint64_t)nb << 8) | cur.level, 0, NULL)) continue;
+            uint32_t idx = 0;
+            if (hset_find(&s->scored, nb, &idx)) stepper_push(s, nb, s->out_and[idx], s->out_or[idx], cur.level);
+            else s->pend[s->n_pend++] = nb;
+        }
+        s->pend_level = cur.level;
+        if (cur.level > 0) {
+            const int nl = cur.level - 1;
+            if (!hset_test_and_set(&s->visited, ((uint64_t)cur.slot << 8) | (uint64_t)nl, 0, NULL))
+                stepper_push(s, cur.slot, cur.and_cnt, cur.or_cnt, nl);
+        }
+        if (s->n_pend) {
+            if (s->n_pend > req_cap) { s->status = -4; return 0; }
+            memcpy(req_out, s->pend, s->n_pend * 4);
+            return (int)s->n_pend;
+        }
+    }
+}
+
+int orc_stepper_status(const orc_stepper_t *s) { return s->status; }
+void orc_stepper_stats(const orc_stepper_t *s, orc_trav_stats_t *st) {
+    memset(st, 0, sizeof *st);
+    st->n_scored = s->n_scored; st->n_pops = s->n_pops; st->n_evals = s->n_scored; st->n_nbr = s->n_nbr;
+}
+uint64_t orc_stepper_results(const orc_stepper_t *s, uint32_t *slots, uint32_t *and_cnt, uint32_t *or_cnt, uint64_t cap) {
+    const uint64_t n = s->n_scored < cap ? s->n_scored : cap;
+    memcpy(slots, s->out_slots, n * 4); memcpy(and_cnt, s->out_and, n * 4); memcpy(or_cnt, s->out_or, n * 4);
+    return s->n_scored;
+}
+uint64_t orc_stepper_pop_log(const orc_stepper_t *s, uint32_t *nodes, uint8_t *levels, uint64_t cap) {
+    const uint64_t m = s->n_pops < s->pop_cap ? s->n_pops : s->pop_cap;
+    const uint64_t n = m < cap ? m : cap;
+    if (n) { memcpy(nodes, s->pop_nodes, n * 4); memcpy(levels, s->pop_levels, n); }
+    return m;
+}
+
 typedef struct {
     const orc_graph_t *g;
     const uint8_t *corpus;

@@ -104,6 +104,20 @@ int orc_rad_traverse_many(const orc_graph_t *g, const uint8_t *corpus,
                           uint64_t n_to_score, int n_threads,
                           orc_trav_stats_t *stats_out /* [nq] */);
 
+/* ---- the same traversal cut at the fingerprint read (row-sharded multi-GPU mode) ----
+ * The control flow of orc_rad_traverse as a stepper that never touches the corpus: one call applies the
+ * (and, or) counts of the slots it asked for last time, then primes / pops / expands until some
+ * neighbour needs a score, and returns those slots.  See rad_oracle.c for the reference lines. */
+typedef struct orc_stepper orc_stepper_t;
+orc_stepper_t *orc_stepper_create(const orc_graph_t *g, uint64_t n_to_score, uint64_t pop_cap);
+void orc_stepper_destroy(orc_stepper_t *s);
+int orc_stepper_step(orc_stepper_t *s, const uint32_t *and_in, const uint32_t *or_in, uint32_t *req_out,
+                     uint32_t req_cap);
+int orc_stepper_status(const orc_stepper_t *s);   /* 0 running, 1 n_to_score reached, 2 queue empty */
+void orc_stepper_stats(const orc_stepper_t *s, orc_trav_stats_t *st);
+uint64_t orc_stepper_results(const orc_stepper_t *s, uint32_t *slots, uint32_t *and_cnt, uint32_t *or_cnt, uint64_t cap);
+uint64_t orc_stepper_pop_log(const orc_stepper_t *s, uint32_t *nodes, uint8_t *levels, uint64_t cap);
+
 /* ---- usearch-shaped HNSW (parity unpinned vs usearch) ---------------- */
 typedef struct orc_hnsw orc_hnsw_t;
 orc_hnsw_t *orc_hnsw_create(uint32_t ndim_bits, uint32_t connectivity,

@@ -42,7 +42,7 @@ class LayoutInfo(C.Structure):
 class TravStats(C.Structure):
     _fields_ = [("n_scored", C.c_uint64), ("n_pops", C.c_uint64), ("n_nbr", C.c_uint64),
                 ("n_repivot", C.c_uint64), ("n_flush", C.c_uint64),
-                ("status", C.c_int32), ("reserved", C.c_int32)]
+                ("status", C.c_int32), ("n_remid", C.c_int32)]
 
 
 _P = C.c_void_p

@@ -76,7 +76,7 @@ struct TravHeader {
     // trav4_kernel's three-level queue: keys below mid_limit are in registers / staging / the mid run
     // [mid_pos, mid_end) of the key pool; the far runs hold keys >= mid_limit only
     uint64_t mid_limit, far_min;
-    uint32_t mid_end, pad;
+    uint32_t mid_end, n_remid;
 };
 
 struct TravParams {
@@ -986,7 +986,7 @@ extern "C" int radhip_traversal_stats(const radhip_traversal_t *t, radhip_trav_s
     for (uint32_t i = 0; i < t->nq; ++i) {
         out[i].n_scored = hdr[i].n_scored; out[i].n_pops = hdr[i].n_pops; out[i].n_nbr = hdr[i].n_nbr;
         out[i].n_repivot = hdr[i].n_repivot; out[i].n_flush = hdr[i].n_flush;
-        out[i].status = hdr[i].status; out[i].reserved = 0;
+        out[i].status = hdr[i].status; out[i].n_remid = (int32_t)hdr[i].n_remid;
     }
     return RADHIP_OK;
 }

@@ -184,11 +184,12 @@ class TraversalStats:
     status: np.ndarray
     n_repivot: np.ndarray = None
     n_flush: np.ndarray = None
+    n_remid: np.ndarray = None
 
 
 # numpy view of _lib.TravStats (include/rad_hip.h radhip_trav_stats_t)
 _TRAV_STATS_DTYPE = np.dtype([("n_scored", "<u8"), ("n_pops", "<u8"), ("n_nbr", "<u8"), ("n_repivot", "<u8"),
-                              ("n_flush", "<u8"), ("status", "<i4"), ("reserved", "<i4")])
+                              ("n_flush", "<u8"), ("status", "<i4"), ("n_remid", "<i4")])
 assert _TRAV_STATS_DTYPE.itemsize == C.sizeof(_lib.TravStats)
 
 
@@ -235,7 +236,7 @@ class DeviceTraversal:
         rec = np.frombuffer(arr, dtype=_TRAV_STATS_DTYPE, count=self.nq)   # one view, no per-record Python
         return TraversalStats(rec["n_scored"].astype(np.int64), rec["n_pops"].astype(np.int64),
                               rec["n_nbr"].astype(np.int64), rec["status"].astype(np.int32),
-                              rec["n_repivot"].astype(np.int64), rec["n_flush"].astype(np.int64))
+                              rec["n_repivot"].astype(np.int64), rec["n_flush"].astype(np.int64), rec["n_remid"].astype(np.int64))
 
     def results(self, q: int):
         """(slots, and, or) of traversal q in traversal order."""

@@ -38,7 +38,7 @@ check(_lib.lib().radhip_search(idx._h, ptr(Q[:64]), 64, k, 64, ptr(s), ptr(a), p
 es, ea, eo, ec = idx.topk(Q[:64], k)
 print("recall@10 (ef 64):", np.mean([len(set(s[i]) & set(es[i])) / k for i in range(64)]), flush=True)
 del X
-for table in ("hash", "group"):
+for table in (os.environ.get("GT_TABLES", "hash,group").split(",")):
     os.environ["RADHIP_TABLE"] = table
     os.environ["RADHIP_TRAV"] = "4"
     if table == "group":
@@ -53,5 +53,5 @@ for table in ("hash", "group"):
         print(f"{table:6s} table={t.table} rep {rep}: {ms:.1f} ms, {st.n_pops.sum() / ms / 1e6:.3f} G expansions/s, {st.n_scored.sum() / ms / 1e6:.2f} G eval/s, "
               f"{st.n_scored.sum() / st.n_pops.sum():.2f} evals/exp, nbr/exp {st.n_nbr.sum() / st.n_pops.sum():.2f}, "
               f"alg GB/s {(st.n_scored.sum() * 132 + st.n_pops.sum() * 4) / ms / 1e6:.0f} state {t.state_bytes() / 2**30:.1f} GiB; "
-              f"per traversal: pops {st.n_pops.mean():.0f} repivots {st.n_repivot.mean():.0f} flushes {st.n_flush.mean():.0f}", flush=True)
+              f"per traversal: pops {st.n_pops.mean():.0f} repivots {st.n_repivot.mean():.0f} flushes {st.n_flush.mean():.0f} remids {st.n_remid.mean():.0f}", flush=True)
     t.close()

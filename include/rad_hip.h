@@ -275,8 +275,51 @@ int radhip_traversal_set_targets(radhip_traversal_t *t, const uint64_t *targets 
  * scored counts — what the ranks all-gather between rounds. */
 int radhip_traversal_frontier(const radhip_traversal_t *t, uint64_t *out_keys, uint64_t *out_scored);
 
-/* ---- multi-GPU exchange: RCCL over xGMI, one process per GPU -------------------- */
+/* ---- row-sharded multi-GPU traversal (BASELINE.json north_star) --------------
+ * One process per GPU.  The corpus is partitioned by contiguous slot range, the layered graph is ONE
+ * graph over all rows (adjacency replicated), and the traversals of a batch are partitioned over the
+ * ranks.  Per frontier step a rank advances each of its traversals to the point where a fingerprint
+ * would be read (the control flow of rad/coordination_service.py:290-413 cut after the visited /
+ * scored tests), the candidate slots of all ranks are all-gathered (RCCL over xGMI), every rank scores
+ * the candidates whose rows it owns, and the scores return to the asking rank (reduce-scatter of
+ * disjoint contributions).  Strict best-first per traversal: results are bit-identical to the
+ * single-GPU traversal of the same corpus and graph for any number of ranks. */
+/* keep rows [first, first+count) of the resident corpus, free the rest (graph, levels, keys stay whole) */
+int radhip_index_keep_rows(radhip_index_t *idx, uint64_t first, uint64_t count);
+typedef struct radhip_shard radhip_shard_t;
 typedef struct radhip_comm radhip_comm_t;
+/* queries_all: world * nq query rows, rank-major — traversal (r, q) belongs to rank r; every rank passes
+ * the same array (it scores other ranks' candidates against their queries).  The index must hold rows
+ * [row_first, row_first+row_count): the whole corpus, or exactly that range after radhip_index_keep_rows. */
+int radhip_shard_create(radhip_index_t *idx, int rank, int world, uint64_t row_first, uint64_t row_count,
+                        const uint8_t *queries_all, uint32_t nq, uint64_t n_to_score, uint32_t flags,
+                        radhip_shard_t **out);
+int radhip_shard_destroy(radhip_shard_t *s);
+/* the product loop: step kernel, ncclAllGather of the candidates, evaluation kernel, ncclReduceScatter of
+ * the scores — device buffers end to end, one stream — until no rank has a live traversal (the live counts
+ * travel behind the candidates, so all ranks stop at the same step) or max_steps (0 = none) */
+int radhip_shard_run(radhip_shard_t *s, radhip_comm_t *comm, uint64_t max_steps, uint64_t *out_steps);
+/* the same step in host-staged pieces, for an exchange the host program owns (tests; rehearsing N ranks
+ * on one GPU): step -> get_requests | exchange | set_requests_all -> evaluate -> get_scores_out |
+ * exchange (sum over ranks of block `rank`) | set_scores_in -> step ...   W = radhip_shard_width() slots
+ * per traversal and step (RADHIP_NO_SLOT padded); scores are and | or << 16. */
+uint32_t radhip_shard_width(const radhip_shard_t *s);
+int radhip_shard_step(radhip_shard_t *s, uint32_t *out_live);
+int radhip_shard_get_requests(radhip_shard_t *s, uint32_t *host /* [nq * W] */);
+int radhip_shard_set_requests_all(radhip_shard_t *s, const uint32_t *host_all /* [world * nq * W] */);
+int radhip_shard_evaluate(radhip_shard_t *s);
+int radhip_shard_get_scores_out(radhip_shard_t *s, uint32_t *host /* [world * nq * W] */);
+int radhip_shard_set_scores_in(radhip_shard_t *s, const uint32_t *host /* [nq * W] */);
+int radhip_shard_stats(const radhip_shard_t *s, radhip_trav_stats_t *out /* [nq] */);
+int radhip_shard_results(const radhip_shard_t *s, uint32_t q, uint32_t *out_slots, uint32_t *out_and,
+                         uint32_t *out_or, uint64_t cap, uint64_t *out_n);
+int radhip_shard_pop_log(const radhip_shard_t *s, uint32_t q, uint32_t *out_nodes, uint8_t *out_levels,
+                         uint64_t cap, uint64_t *out_n);
+int radhip_shard_timing(const radhip_shard_t *s, double *out_step_ms, double *out_eval_ms, uint64_t *out_steps,
+                        uint64_t *out_exchanged_bytes);
+uint64_t radhip_shard_state_bytes(const radhip_shard_t *s);
+
+/* ---- multi-GPU exchange: RCCL over xGMI, one process per GPU -------------------- */
 int radhip_comm_unique_id(uint8_t *out128);          /* rank 0 creates, host hands to others */
 int radhip_comm_create(int rank, int world, const uint8_t *id128, int device, radhip_comm_t **out);
 int radhip_comm_destroy(radhip_comm_t *c);

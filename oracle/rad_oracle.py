@@ -71,6 +71,18 @@ def lib():
         L.orc_synth_max_level.argtypes = [C.c_uint64, C.c_uint32]
         L.orc_synth_upper_rows.restype = C.c_uint64
         L.orc_synth_upper_rows.argtypes = [C.c_uint64, C.c_uint32]
+        L.orc_stepper_create.restype = C.c_void_p
+        L.orc_stepper_create.argtypes = [C.POINTER(_Graph), C.c_uint64, C.c_uint64]
+        L.orc_stepper_destroy.argtypes = [C.c_void_p]
+        L.orc_stepper_step.restype = C.c_int
+        L.orc_stepper_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_stepper_status.restype = C.c_int
+        L.orc_stepper_status.argtypes = [C.c_void_p]
+        L.orc_stepper_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
+        L.orc_stepper_results.restype = C.c_uint64
+        L.orc_stepper_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.orc_stepper_pop_log.restype = C.c_uint64
+        L.orc_stepper_pop_log.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         _lib = L
     return _lib
 
@@ -204,6 +216,48 @@ def rad_traverse_many(graph: Graph, corpus: np.ndarray, queries: np.ndarray, n_t
         raise RuntimeError(f"orc_rad_traverse_many failed rc={rc}")
     return (np.array([x.n_scored for x in st]), np.array([x.n_pops for x in st]),
             np.array([x.n_nbr for x in st]))
+
+
+class Stepper:
+    """orc_stepper: the traversal of rad_traverse cut at the fingerprint read.  step(and, or) applies the
+    counts of the slots returned by the previous call and returns the next slots that need a score (an
+    empty array once the traversal has ended).  It never touches the corpus."""
+
+    def __init__(self, graph: Graph, n_to_score: int, log_pops: bool = True):
+        self._g = graph
+        self._gs = graph.c_struct()          # keeps the arrays alive
+        self._cap = int(n_to_score) * 2 + 4096 + int(graph.n if graph.n < 65536 else 65536)
+        self._h = lib().orc_stepper_create(C.byref(self._gs), C.c_uint64(n_to_score), C.c_uint64(self._cap if log_pops else 0))
+        self._req = np.empty(64, np.uint32)
+        self.width = max(graph.cap0, graph.capU)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_stepper_destroy(self._h)
+            self._h = None
+
+    def step(self, and_in=None, or_in=None) -> np.ndarray:
+        a = np.ascontiguousarray(and_in if and_in is not None else np.empty(0), np.uint32)
+        o = np.ascontiguousarray(or_in if or_in is not None else np.empty(0), np.uint32)
+        n = lib().orc_stepper_step(self._h, _p(a), _p(o), _p(self._req), C.c_uint32(self.width))
+        st = self.status
+        if st < 0:
+            raise RuntimeError(f"orc_stepper_step failed, status {st}")
+        return self._req[:n].copy()
+
+    @property
+    def status(self) -> int:
+        return int(lib().orc_stepper_status(self._h))
+
+    def result(self) -> TraverseResult:
+        st = _Stats()
+        lib().orc_stepper_stats(self._h, C.byref(st))
+        k = int(st.n_scored)
+        s = np.empty(k, np.uint32); a = np.empty(k, np.uint32); o = np.empty(k, np.uint32)
+        lib().orc_stepper_results(self._h, _p(s), _p(a), _p(o), C.c_uint64(k))
+        pn = np.empty(self._cap, np.uint32); pl = np.empty(self._cap, np.uint8)
+        m = int(lib().orc_stepper_pop_log(self._h, _p(pn), _p(pl), C.c_uint64(self._cap)))
+        return TraverseResult(s, a, o, pn[:m].copy(), pl[:m].copy(), int(st.n_pops), int(st.n_nbr))
 
 
 class Hnsw:

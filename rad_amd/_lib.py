@@ -96,6 +96,22 @@ SIGNATURES = {
     "radhip_traversal_table": (C.c_int, [_P]),
     "radhip_traversal_set_targets": (C.c_int, [_P, _P]),
     "radhip_traversal_frontier": (C.c_int, [_P, _P, _P]),
+    "radhip_index_keep_rows": (C.c_int, [_P, _U64, _U64]),
+    "radhip_shard_create": (C.c_int, [_P, C.c_int, C.c_int, _U64, _U64, _P, _U32, _U64, _U32, C.POINTER(_P)]),
+    "radhip_shard_destroy": (C.c_int, [_P]),
+    "radhip_shard_run": (C.c_int, [_P, _P, _U64, C.POINTER(_U64)]),
+    "radhip_shard_width": (_U32, [_P]),
+    "radhip_shard_step": (C.c_int, [_P, C.POINTER(_U32)]),
+    "radhip_shard_get_requests": (C.c_int, [_P, _P]),
+    "radhip_shard_set_requests_all": (C.c_int, [_P, _P]),
+    "radhip_shard_evaluate": (C.c_int, [_P]),
+    "radhip_shard_get_scores_out": (C.c_int, [_P, _P]),
+    "radhip_shard_set_scores_in": (C.c_int, [_P, _P]),
+    "radhip_shard_stats": (C.c_int, [_P, _P]),
+    "radhip_shard_results": (C.c_int, [_P, _U32, _P, _P, _P, _U64, C.POINTER(_U64)]),
+    "radhip_shard_pop_log": (C.c_int, [_P, _U32, _P, _P, _U64, C.POINTER(_U64)]),
+    "radhip_shard_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_U64), C.POINTER(_U64)]),
+    "radhip_shard_state_bytes": (_U64, [_P]),
     "radhip_comm_unique_id": (C.c_int, [_P]),
     "radhip_comm_create": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, C.POINTER(_P)]),
     "radhip_comm_destroy": (C.c_int, [_P]),

@@ -547,6 +547,7 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
     if (max_batch < 1) max_batch = 1;
     if (max_batch > 65536) max_batch = 65536;
     std::lock_guard<std::mutex> lk(idx->mu);
+    RH_REQUIRE_FULL_CORPUS(idx);
     if (idx->has_graph && !idx->h_graph_valid && idx->g_n) {
         // graph generated on the device (synthetic): mirror levels / upper rows first
         RH_TRY(rh_ensure_host_graph(idx));
@@ -740,6 +741,7 @@ extern "C" int radhip_search(radhip_index_t *idx, const uint8_t *queries, uint32
                              uint64_t *out_evals, uint64_t *out_pops) {
     if (!idx || !queries || !out_slots || !out_counts) RH_FAIL(RADHIP_E_INVALID, "null argument");
     if (!idx->has_vectors || !idx->has_graph) RH_FAIL(RADHIP_E_STATE, "index needs vectors and a graph");
+    RH_REQUIRE_FULL_CORPUS(idx);
     if (nq == 0 || k == 0) return RADHIP_OK;
     if (ef < k) ef = k;
     std::lock_guard<std::mutex> lk(idx->mu);

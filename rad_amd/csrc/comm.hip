@@ -1,20 +1,10 @@
 // comm.hip — RCCL communicator behind the C ABI: the exchange step of the sharded
 // traversal (per-round all-gather of frontier candidate scores / scored counts over xGMI).
 // One process per GPU; the ncclUniqueId is created by rank 0 and handed to the other ranks
-// by the host program (bench.py uses torch.distributed only for that hand-off and barriers).
-#include "common.h"
-
-#include <rccl/rccl.h>
+// by the host program (bench.py: a plain TCP rendezvous, rad_amd/rendezvous.py; no torch).
+#include "comm.h"
 
 #include <new>
-
-struct radhip_comm {
-    ncclComm_t comm = nullptr;
-    int rank = 0, world = 1, device = 0;
-    hipStream_t stream = nullptr;
-    void *d_send = nullptr, *d_recv = nullptr;
-    size_t cap_send = 0, cap_recv = 0;
-};
 
 #define RH_NCCL(expr)                                                                   \
     do {                                                                                \
@@ -93,6 +83,26 @@ extern "C" int radhip_comm_allgather_u64(radhip_comm_t *c, const uint64_t *send,
     RH_NCCL(ncclAllGather(c->d_send, c->d_recv, count, ncclUint64, c->comm, c->stream));
     RH_HIP(hipMemcpyAsync(recv, c->d_recv, rb, hipMemcpyDeviceToHost, c->stream));
     RH_HIP(hipStreamSynchronize(c->stream));
+    return RADHIP_OK;
+}
+
+// ---- device-buffer collectives of the row-sharded traversal (shard.hip): frontier candidates out with
+// ncclAllGather, their scores back with ncclReduceScatter (every candidate is scored by the one rank that
+// owns its row, the others contribute 0), both on the stream the kernels run on
+int rh_comm_allgather_dev(radhip_comm *c, const uint32_t *d_send, uint32_t *d_recv, size_t count_u32, hipStream_t st) {
+    if (c->world == 1) {
+        RH_HIP(hipMemcpyAsync(d_recv, d_send, count_u32 * 4, hipMemcpyDeviceToDevice, st));
+        return RADHIP_OK;
+    }
+    RH_NCCL(ncclAllGather(d_send, d_recv, count_u32, ncclUint32, c->comm, st));
+    return RADHIP_OK;
+}
+int rh_comm_reduce_scatter_u32_dev(radhip_comm *c, const uint32_t *d_send, uint32_t *d_recv, size_t count_u32, hipStream_t st) {
+    if (c->world == 1) {
+        RH_HIP(hipMemcpyAsync(d_recv, d_send, count_u32 * 4, hipMemcpyDeviceToDevice, st));
+        return RADHIP_OK;
+    }
+    RH_NCCL(ncclReduceScatter(d_send, d_recv, count_u32, ncclUint32, ncclSum, c->comm, st));
     return RADHIP_OK;
 }
 

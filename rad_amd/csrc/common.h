@@ -42,7 +42,9 @@ struct radhip_index {
     uint32_t ndim_bits = 0, row_bytes = 0, row_stride = 0, lpr = 0;  // lpr = 16-B lanes per row
     uint32_t M = 0, cap0 = 0, ef_add = 0;
     int device = 0;
-    uint64_t n = 0;           // rows in the corpus
+    uint64_t n = 0;           // rows resident in d_fp
+    bool sharded = false;
+    uint64_t shard_first = 0; // slot of row 0 of d_fp: 0 unless radhip_index_keep_rows dropped the rows of the other ranks
     // ---- host mirror (adjacency reads need no device: fork-safe) ----------
     uint64_t g_n = 0;         // nodes in the graph
     int32_t max_level = -1;
@@ -93,6 +95,13 @@ void rh_layout_invalidate(radhip_index *idx);      // layout.hip: the graph chan
 int rh_optimize_layout_locked(radhip_index *idx, uint32_t n_threads);   // idx->mu held by the caller
 
 int rh_ensure_device(radhip_index *idx);           // lazy HIP init + pending uploads
+// entry points that address d_fp by slot refuse an index that keeps only its shard of the rows
+#define RH_REQUIRE_FULL_CORPUS(idx)                                                                        \
+    do {                                                                                                   \
+        if ((idx)->sharded) RH_FAIL(RADHIP_E_STATE, "this index keeps rows [%llu, %llu) only (radhip_index_keep_rows): " \
+                                    "use the sharded traversal", (unsigned long long)(idx)->shard_first,   \
+                                    (unsigned long long)((idx)->shard_first + (idx)->n));                  \
+    } while (0)
 int rh_ensure_host_graph(radhip_index *idx);       // D2H mirror of a device-generated graph
 
 // ------------------------------------------------- device-side primitives --

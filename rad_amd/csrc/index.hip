@@ -211,6 +211,7 @@ extern "C" int radhip_index_load_vectors(radhip_index_t *idx, const uint8_t *row
         (void)tail_bits;  // padding bits beyond ndim are the caller's (np.packbits zero-fills them)
     }
     idx->n = n;
+    idx->sharded = false; idx->shard_first = 0;
     idx->h_rows_pending = true;
     idx->has_vectors = true;
     idx->graph_gen++;
@@ -318,6 +319,7 @@ extern "C" int radhip_index_synth_vectors(radhip_index_t *idx, uint64_t n, uint6
     RH_TRY(dev_alloc(idx, (void **)&idx->d_fp, n * idx->row_stride));
     idx->fp_cap_rows = n;
     idx->n = n;
+    idx->sharded = false; idx->shard_first = 0;
     uint32_t wps = idx->row_stride / 8;
     hipLaunchKernelGGL(synth_rows_kernel, dim3(256 * 16), dim3(256), 0, idx->stream, (uint64_t *)idx->d_fp, n,
                        wps, idx->row_bytes, idx->ndim_bits, first_row, n_total, seed, mode);
@@ -328,11 +330,37 @@ extern "C" int radhip_index_synth_vectors(radhip_index_t *idx, uint64_t n, uint6
     return RADHIP_OK;
 }
 
+// Row-sharded multi-GPU mode: this rank keeps rows [first, first + count) of the corpus it generated /
+// loaded in full (the graph is built over all rows first; adjacency, levels and keys stay whole).
+extern "C" int radhip_index_keep_rows(radhip_index_t *idx, uint64_t first, uint64_t count) {
+    if (!idx) RH_FAIL(RADHIP_E_INVALID, "null index");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (!idx->has_vectors) RH_FAIL(RADHIP_E_STATE, "no vectors loaded");
+    RH_REQUIRE_FULL_CORPUS(idx);
+    if (count == 0 || first + count > idx->n) RH_FAIL(RADHIP_E_RANGE, "rows [%llu, %llu) out of range (%llu rows)",
+                                                      (unsigned long long)first, (unsigned long long)(first + count),
+                                                      (unsigned long long)idx->n);
+    RH_TRY(rh_ensure_device(idx));
+    uint4 *nfp = nullptr;
+    RH_HIP(hipMalloc((void **)&nfp, count * idx->row_stride));
+    RH_HIP(hipMemcpy(nfp, (const uint8_t *)idx->d_fp + first * idx->row_stride, count * idx->row_stride, hipMemcpyDeviceToDevice));
+    dev_free(idx, idx->d_fp, idx->fp_cap_rows * idx->row_stride);
+    idx->d_fp = nfp;
+    idx->device_bytes += count * idx->row_stride;
+    idx->fp_cap_rows = count;
+    idx->n = count;
+    idx->shard_first = first;
+    idx->sharded = true;
+    idx->graph_gen++;
+    return RADHIP_OK;
+}
+
 extern "C" int radhip_index_read_vectors(const radhip_index_t *cidx, uint64_t first, uint64_t count,
                                          uint8_t *out_rows) {
     radhip_index *idx = const_cast<radhip_index *>(cidx);
     if (!idx || !out_rows) RH_FAIL(RADHIP_E_INVALID, "null argument");
     if (!idx->has_vectors) RH_FAIL(RADHIP_E_STATE, "no vectors loaded");
+    RH_REQUIRE_FULL_CORPUS(idx);
     if (first + count > idx->n) RH_FAIL(RADHIP_E_RANGE, "rows out of range");
     std::lock_guard<std::mutex> lk(idx->mu);
     RH_TRY(rh_ensure_device(idx));
@@ -668,6 +696,7 @@ extern "C" int radhip_tanimoto_scan(radhip_index_t *idx, const uint8_t *queries,
                                     uint64_t first, uint64_t count, uint32_t *and_out, uint32_t *or_out) {
     if (!idx || !queries || !and_out || !or_out) RH_FAIL(RADHIP_E_INVALID, "null argument");
     if (!idx->has_vectors) RH_FAIL(RADHIP_E_STATE, "no vectors loaded");
+    RH_REQUIRE_FULL_CORPUS(idx);
     if (first + count > idx->n) RH_FAIL(RADHIP_E_RANGE, "rows [first, first+count) out of range");
     if (nq == 0 || count == 0) return RADHIP_OK;
     std::lock_guard<std::mutex> lk(idx->mu);
@@ -795,6 +824,7 @@ extern "C" int radhip_tanimoto_gather(radhip_index_t *idx, const uint8_t *querie
                                       uint32_t *and_out, uint32_t *or_out) {
     if (!idx || !queries || !cand_offsets) RH_FAIL(RADHIP_E_INVALID, "null argument");
     if (!idx->has_vectors) RH_FAIL(RADHIP_E_STATE, "no vectors loaded");
+    RH_REQUIRE_FULL_CORPUS(idx);
     const uint64_t n_pairs = nq ? cand_offsets[nq] : 0;
     if (n_pairs == 0) return RADHIP_OK;
     if (!cand_slots || !and_out || !or_out) RH_FAIL(RADHIP_E_INVALID, "null argument");

@@ -1,0 +1,561 @@
+// shard.hip — the row-sharded multi-GPU traversal (BASELINE.json north_star): the
+// fingerprint corpus is partitioned over the GPUs of a node by contiguous slot range, ONE layered graph
+// (adjacency replicated), and the traversals of a batch are partitioned over the ranks too.  Per frontier
+// step every rank
+//   1. advances each of ITS traversals to the point where a fingerprint would be read: apply the scores that
+//      came back for the last step (scored insert + queue insert, rad/coordination_service.py:379-389), then
+//      pop / expand (visited test-and-set, rad/visited.py:17-29) until some neighbour is not in the scored
+//      set (rad/distributed_worker.py:296-305) — those slots are the step's frontier candidates;
+//   2. all-gathers the candidates of all ranks (RCCL ncclAllGather over xGMI);
+//   3. evaluates the candidates whose rows it owns against the query of the traversal that asked
+//      (Tanimoto counts, the K2 gather shape);
+//   4. returns the scores to the asking ranks (ncclReduceScatter of disjoint contributions: every candidate
+//      is owned by exactly one rank, the others add 0).
+// The control flow per traversal is exactly the single-GPU one (strict best-first, one pop at a time), so
+// the scored lists and pop logs are bit-identical to a single-GPU traversal of the same corpus and graph
+// whatever the number of ranks (tests/test_sharded.py on CPU with the oracle's stepper as the local
+// engine, tests/test_gpu_sharded.py through these kernels).  What is exchanged per step and rank:
+// nq x W candidate slots (4 B each) out, nq x W packed (and | or << 16) scores back.
+//
+// The step kernel is deliberately simple — one thread per traversal, binary heap and open-addressed sets
+// in HBM, the oracle's stepper restated (oracle/rad_oracle.c orc_stepper_step): a sharded step is bound by
+// the two collectives between its kernels, not by them.
+#include "common.h"
+#include "comm.h"
+
+#include <algorithm>
+#include <new>
+
+#define SH_EMPTY64 0ull
+
+struct ShardHeader {
+    uint64_t n_scored, n_pops, n_nbr, heap_n;
+    uint32_t prime_at, n_pend, pend_level;
+    int32_t status;      // 0 running, 1 n_to_score reached, 2 queue empty, < 0 error
+};
+
+struct ShardParams {
+    const uint32_t *adj0, *upper_row, *adjU, *top;
+    uint32_t n_top, cap0, capU, nq, W;
+    int32_t start_level;
+    uint64_t n_to_score;
+    ShardHeader *hdr;
+    unsigned long long *heap; uint64_t heap_cap;
+    unsigned long long *vis; uint32_t vlog2;      // ((slot << 4) | level) + 1
+    unsigned long long *sc; uint32_t slog2;       // (slot + 1) | packed counts << 32
+    uint2 *scored; uint64_t scored_cap;
+    uint32_t *req;               // [nq * W + 16]: candidate slots of this step, then the live count
+    const uint32_t *scores_in;   // [nq * W]: and | or << 16 of the previous step's candidates
+    uint32_t *poplog_nodes; uint8_t *poplog_levels; uint64_t poplog_cap;
+    uint32_t max_inner;          // pops per step at most while nothing needs a score
+};
+
+__device__ __forceinline__ uint64_t sh_h64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+// true if the key was already present, else inserts it
+__device__ __forceinline__ bool sh_vis_tas(unsigned long long *vis, uint32_t vlog2, uint32_t slot, uint32_t level) {
+    const unsigned long long k1 = (((unsigned long long)slot << 4) | level) + 1ull;
+    const uint64_t mask = (1ull << vlog2) - 1ull;
+    uint64_t i = sh_h64(k1) & mask;
+    for (;;) {
+        const unsigned long long e = vis[i];
+        if (e == SH_EMPTY64) { vis[i] = k1; return false; }
+        if (e == k1) return true;
+        i = (i + 1) & mask;
+    }
+}
+__device__ __forceinline__ bool sh_sc_find(const unsigned long long *sc, uint32_t slog2, uint32_t slot, uint32_t *val) {
+    const uint64_t mask = (1ull << slog2) - 1ull;
+    uint64_t i = sh_h64((uint64_t)slot + 1ull) & mask;
+    for (;;) {
+        const unsigned long long e = sc[i];
+        if (e == SH_EMPTY64) return false;
+        if ((uint32_t)e == slot + 1u) { *val = (uint32_t)(e >> 32); return true; }
+        i = (i + 1) & mask;
+    }
+}
+__device__ __forceinline__ void sh_sc_insert(unsigned long long *sc, uint32_t slog2, uint32_t slot, uint32_t val) {
+    const uint64_t mask = (1ull << slog2) - 1ull;
+    uint64_t i = sh_h64((uint64_t)slot + 1ull) & mask;
+    while (sc[i] != SH_EMPTY64) i = (i + 1) & mask;
+    sc[i] = (unsigned long long)(slot + 1u) | ((unsigned long long)val << 32);
+}
+__device__ __forceinline__ void sh_heap_push(unsigned long long *h, uint64_t &n, unsigned long long key) {
+    uint64_t i = n++;
+    while (i > 0) {
+        const uint64_t p = (i - 1) >> 1;
+        const unsigned long long pk = h[p];
+        if (pk <= key) break;
+        h[i] = pk;
+        i = p;
+    }
+    h[i] = key;
+}
+__device__ __forceinline__ unsigned long long sh_heap_pop(unsigned long long *h, uint64_t &n) {
+    const unsigned long long top = h[0];
+    const unsigned long long last = h[--n];
+    uint64_t i = 0;
+    for (;;) {
+        const uint64_t l = 2 * i + 1, r = l + 1;
+        if (l >= n) break;
+        uint64_t m = l;
+        unsigned long long mk = h[l];
+        if (r < n) { const unsigned long long rk = h[r]; if (rk < mk) { m = r; mk = rk; } }
+        if (mk >= last) break;
+        h[i] = mk;
+        i = m;
+    }
+    if (n) h[i] = last;
+    return top;
+}
+
+__global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= P.nq) return;
+    ShardHeader H = P.hdr[q];
+    uint32_t *req = P.req + (uint64_t)q * P.W;
+    if (H.status != 0) {
+        if (H.n_pend) { for (uint32_t i = 0; i < P.W; ++i) req[i] = RADHIP_NO_SLOT; H.n_pend = 0; P.hdr[q] = H; }
+        return;
+    }
+    unsigned long long *heap = P.heap + (uint64_t)q * P.heap_cap;
+    unsigned long long *vis = P.vis + ((uint64_t)q << P.vlog2);
+    unsigned long long *sc = P.sc + ((uint64_t)q << P.slog2);
+    uint2 *scored = P.scored + (uint64_t)q * P.scored_cap;
+    const uint32_t *sin = P.scores_in + (uint64_t)q * P.W;
+    // ---- finish: the candidates of the last step are scored now (scored insert, queue insert)
+    for (uint32_t i = 0; i < H.n_pend; ++i) {
+        const uint32_t slot = req[i], v = sin[i];
+        if (H.n_scored >= P.scored_cap || H.heap_n >= P.heap_cap) { H.status = RADHIP_E_CAPACITY; break; }
+        scored[H.n_scored++] = make_uint2(slot, v);
+        sh_sc_insert(sc, P.slog2, slot, v);
+        sh_heap_push(heap, H.heap_n, rh_make_key_dev(rh_q24_dev(v & 0xFFFFu, v >> 16), slot, H.pend_level));
+    }
+    H.n_pend = 0;
+    uint32_t k = 0;
+    if (H.status == 0 && H.prime_at < P.n_top) {
+        // ---- prime (rad/traverser.py:141-170): W top-level nodes per step; distinct, nothing scored yet
+        while (H.prime_at < P.n_top && k < P.W) {
+            const uint32_t slot = P.top[H.prime_at++];
+            (void)sh_vis_tas(vis, P.vlog2, slot, (uint32_t)P.start_level);
+            req[k++] = slot;
+        }
+        H.pend_level = (uint32_t)P.start_level;
+    } else if (H.status == 0) {
+        // ---- pop / expand until a neighbour needs a score (or max_inner pops without one)
+        for (uint32_t it = 0; it < P.max_inner; ++it) {
+            if (H.n_scored >= P.n_to_score) { H.status = 1; break; }
+            if (H.heap_n == 0) { H.status = 2; break; }
+            const unsigned long long key = sh_heap_pop(heap, H.heap_n);
+            uint32_t slot, level;
+            rh_decode_key(key, &slot, &level);
+            if (P.poplog_nodes && H.n_pops < P.poplog_cap) {
+                P.poplog_nodes[(uint64_t)q * P.poplog_cap + H.n_pops] = slot;
+                P.poplog_levels[(uint64_t)q * P.poplog_cap + H.n_pops] = (uint8_t)level;
+            }
+            H.n_pops++;
+            const uint32_t cap = level == 0 ? P.cap0 : P.capU;
+            const uint32_t *row = level == 0 ? P.adj0 + (uint64_t)slot * P.cap0
+                                             : P.adjU + ((uint64_t)P.upper_row[slot] + (level - 1u)) * P.capU;
+            for (uint32_t j = 0; j < cap; ++j) {
+                const uint32_t nb = row[j];
+                if (nb == RADHIP_NO_SLOT) break;
+                H.n_nbr++;
+                if (sh_vis_tas(vis, P.vlog2, nb, level)) continue;
+                uint32_t v;
+                if (sh_sc_find(sc, P.slog2, nb, &v)) {
+                    if (H.heap_n >= P.heap_cap) { H.status = RADHIP_E_CAPACITY; break; }
+                    sh_heap_push(heap, H.heap_n, rh_make_key_dev(rh_q24_dev(v & 0xFFFFu, v >> 16), nb, level));
+                } else req[k++] = nb;
+            }
+            H.pend_level = level;
+            if (H.status == 0 && level > 0) {
+                const uint32_t nl = level - 1u;
+                if (!sh_vis_tas(vis, P.vlog2, slot, nl)) {
+                    if (H.heap_n >= P.heap_cap) H.status = RADHIP_E_CAPACITY;
+                    else sh_heap_push(heap, H.heap_n, rh_make_key_dev((uint32_t)(key >> 38), slot, nl));
+                }
+            }
+            if (k || H.status != 0) break;
+        }
+    }
+    for (uint32_t i = k; i < P.W; ++i) req[i] = RADHIP_NO_SLOT;
+    H.n_pend = k;
+    P.hdr[q] = H;
+    if (H.status == 0) atomicAdd(&P.req[(uint64_t)P.nq * P.W], 1u);   // live traversals of this rank
+}
+
+// ---- candidates of every rank x the rows this rank owns: LPR lanes per candidate, U in flight per lane
+struct EvalParams {
+    const uint4 *fp;             // rows [first, first + count) of the corpus
+    uint64_t first, count;
+    const uint4 *queries;        // [world * nq] query rows (padded to the row stride)
+    const uint32_t *qpop;        // [world * nq]
+    const uint32_t *req_all;     // [world][nq * W + 16]
+    uint32_t *out;               // [world][nq * W]
+    uint32_t world, nq, W;
+};
+
+template <int LPR>
+__global__ __launch_bounds__(256) void shard_eval_kernel(EvalParams P) {
+    constexpr int GPW = 64 / LPR, U = 4;
+    const uint32_t lane = threadIdx.x & 63u, chunk = lane % LPR, grp = lane / LPR;
+    const uint64_t per_rank = (uint64_t)P.nq * P.W, total = per_rank * P.world;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t base = wave * (GPW * U); base < total; base += n_waves * (GPW * U)) {
+        uint32_t sl[U];
+        uint64_t at[U];
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            at[u] = base + (uint64_t)u * GPW + grp;
+            sl[u] = RADHIP_NO_SLOT;
+            if (at[u] < total) {
+                const uint64_t r = at[u] / per_rank, off = at[u] - r * per_rank;
+                sl[u] = P.req_all[r * (per_rank + 16u) + off];
+            }
+            const bool mine = sl[u] != RADHIP_NO_SLOT && sl[u] >= P.first && sl[u] < P.first + P.count;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (mine) v[u] = P.fp[((uint64_t)sl[u] - P.first) * LPR + chunk];
+            else sl[u] = RADHIP_NO_SLOT;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t res = 0u;
+            if (sl[u] != RADHIP_NO_SLOT) {
+                const uint64_t tq = at[u] / P.W;              // global traversal number = rank * nq + q
+                const uint4 qv = P.queries[tq * LPR + chunk];
+                const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v[u]));
+                const uint32_t a = rh_group_sum<LPR>(rh_popc4_and(v[u], qv));
+                res = a | ((P.qpop[tq] + rp - a) << 16);
+            } else {
+                (void)rh_group_sum<LPR>(0u); (void)rh_group_sum<LPR>(0u);
+            }
+            if (chunk == 0 && at[u] < total) P.out[at[u]] = res;
+        }
+    }
+}
+
+// ================================================================== host side
+struct radhip_shard {
+    radhip_index *idx = nullptr;
+    int rank = 0, world = 1;
+    uint32_t nq = 0, W = 0;
+    uint64_t n_to_score = 0, first = 0, count = 0;
+    ShardParams P{};
+    EvalParams E{};
+    uint4 *d_queries = nullptr;
+    uint32_t *d_qpop = nullptr, *d_req = nullptr, *d_req_all = nullptr, *d_out = nullptr, *d_in = nullptr;
+    uint64_t graph_gen = 0;
+    size_t state_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double step_ms = 0.0, eval_ms = 0.0;
+    uint64_t steps = 0, exchanged_bytes = 0;
+};
+
+static uint32_t sh_log2_ceil(uint64_t x) { uint32_t l = 0; while (((uint64_t)1 << l) < x) l++; return l; }
+
+extern "C" int radhip_shard_destroy(radhip_shard_t *s) {
+    if (!s) return RADHIP_OK;
+    if (s->idx && s->idx->dev_ready) (void)hipSetDevice(s->idx->device);
+    void *ps[] = {s->d_queries, s->d_qpop, s->d_req, s->d_req_all, s->d_out, s->d_in, s->P.hdr, s->P.heap, s->P.vis, s->P.sc,
+                  s->P.scored, s->P.poplog_nodes, s->P.poplog_levels};
+    for (void *p : ps) if (p) (void)hipFree(p);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uint64_t row_first, uint64_t row_count,
+                                   const uint8_t *queries_all, uint32_t nq, uint64_t n_to_score, uint32_t flags,
+                                   radhip_shard_t **out) {
+    if (!idx || !queries_all || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (world < 1 || rank < 0 || rank >= world || nq == 0 || n_to_score == 0) RH_FAIL(RADHIP_E_INVALID, "bad argument");
+    if (!idx->has_vectors || !idx->has_graph) RH_FAIL(RADHIP_E_STATE, "index needs vectors and a graph");
+    if (idx->g_n > 1000000000ull) RH_FAIL(RADHIP_E_INVALID, "RAD traversal needs slots < 1e9");
+    if (row_first + row_count > idx->g_n) RH_FAIL(RADHIP_E_RANGE, "rows [%llu, %llu) exceed the graph's %llu nodes",
+                                                  (unsigned long long)row_first, (unsigned long long)(row_first + row_count),
+                                                  (unsigned long long)idx->g_n);
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_TRY(rh_ensure_device(idx));
+    // the rows this rank evaluates must be resident: either the whole corpus or exactly this shard
+    if (!(idx->shard_first <= row_first && row_first + row_count <= idx->shard_first + idx->n))
+        RH_FAIL(RADHIP_E_STATE, "rows [%llu, %llu) are not resident in this index (it holds [%llu, %llu))",
+                (unsigned long long)row_first, (unsigned long long)(row_first + row_count),
+                (unsigned long long)idx->shard_first, (unsigned long long)(idx->shard_first + idx->n));
+    radhip_shard *s = new (std::nothrow) radhip_shard();
+    if (!s) RH_FAIL(RADHIP_E_NOMEM, "out of host memory");
+    s->idx = idx; s->rank = rank; s->world = world; s->nq = nq; s->n_to_score = std::min<uint64_t>(n_to_score, idx->g_n);
+    s->first = row_first; s->count = row_count; s->graph_gen = idx->graph_gen;
+    const uint32_t W = std::max<uint32_t>(idx->cap0, idx->M);
+    s->W = W;
+    const uint64_t n_top = idx->n_top;
+    const uint64_t scored_cap = s->n_to_score + W + n_top;
+    const uint64_t up_pairs = idx->n_upper_rows + n_top * (uint64_t)(idx->max_level + 1);
+    const uint64_t heap_cap = scored_cap + std::min<uint64_t>(up_pairs, scored_cap * (uint64_t)(idx->max_level + 1)) + 64;
+    const uint32_t vlog2 = std::max<uint32_t>(8, sh_log2_ceil(2 * heap_cap));
+    const uint32_t slog2 = std::max<uint32_t>(8, sh_log2_ceil(2 * scored_cap));
+    ShardParams &P = s->P;
+    P.adj0 = idx->d_adj0; P.upper_row = idx->d_upper_row; P.adjU = idx->d_adjU; P.top = idx->d_top;
+    P.n_top = idx->n_top; P.cap0 = idx->cap0; P.capU = idx->M; P.nq = nq; P.W = W;
+    P.start_level = idx->max_level > 0 ? idx->max_level - 1 : 0;
+    P.n_to_score = s->n_to_score; P.heap_cap = heap_cap; P.vlog2 = vlog2; P.slog2 = slog2; P.scored_cap = scored_cap;
+    P.max_inner = 8;
+    int rc = RADHIP_OK;
+    const size_t per_rank = (size_t)nq * W;
+    auto al = [&](void **p, size_t bytes, bool zero) {
+        if (rc != RADHIP_OK) return;
+        hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+        if (e != hipSuccess) {
+            radhip_set_error("hipMalloc(%zu) for the sharded traversal state failed: %s", bytes, hipGetErrorString(e));
+            rc = e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP;
+            return;
+        }
+        s->state_bytes += bytes;
+        if (zero && hipMemsetAsync(*p, 0, bytes ? bytes : 16, idx->stream) != hipSuccess) rc = RADHIP_E_HIP;
+    };
+    al((void **)&P.hdr, (size_t)nq * sizeof(ShardHeader), true);
+    al((void **)&P.heap, (size_t)nq * heap_cap * 8, false);
+    al((void **)&P.vis, ((size_t)nq << vlog2) * 8, true);
+    al((void **)&P.sc, ((size_t)nq << slog2) * 8, true);
+    al((void **)&P.scored, (size_t)nq * scored_cap * sizeof(uint2), false);
+    al((void **)&s->d_req, (per_rank + 16) * 4, true);
+    al((void **)&s->d_req_all, (size_t)world * (per_rank + 16) * 4, true);
+    al((void **)&s->d_out, (size_t)world * per_rank * 4, true);
+    al((void **)&s->d_in, per_rank * 4, true);
+    al((void **)&s->d_queries, (size_t)world * nq * idx->row_stride, false);
+    al((void **)&s->d_qpop, (size_t)world * nq * 4, false);
+    if (flags & RADHIP_TRAV_LOG_POPS) {
+        P.poplog_cap = heap_cap;
+        al((void **)&P.poplog_nodes, (size_t)nq * heap_cap * 4, false);
+        al((void **)&P.poplog_levels, (size_t)nq * heap_cap, false);
+    }
+    if (rc == RADHIP_OK && (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess)) rc = RADHIP_E_HIP;
+    if (rc == RADHIP_OK) {
+        const size_t tq = (size_t)world * nq;
+        std::vector<uint8_t> padded(tq * idx->row_stride, 0);
+        std::vector<uint32_t> pop(tq, 0);
+        for (size_t i = 0; i < tq; ++i) {
+            memcpy(padded.data() + i * idx->row_stride, queries_all + i * idx->row_bytes, idx->row_bytes);
+            uint32_t p = 0;
+            for (uint32_t b = 0; b < idx->row_bytes; ++b) p += (uint32_t)__builtin_popcount(queries_all[i * idx->row_bytes + b]);
+            pop[i] = p;
+        }
+        if (hipMemcpyAsync(s->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, idx->stream) != hipSuccess ||
+            hipMemcpyAsync(s->d_qpop, pop.data(), tq * 4, hipMemcpyHostToDevice, idx->stream) != hipSuccess ||
+            hipStreamSynchronize(idx->stream) != hipSuccess) {
+            radhip_set_error("query upload failed");
+            rc = RADHIP_E_HIP;
+        }
+    }
+    if (rc != RADHIP_OK) { radhip_shard_destroy(s); return rc; }
+    P.req = s->d_req; P.scores_in = s->d_in;
+    EvalParams &E = s->E;
+    E.fp = idx->d_fp + (row_first - idx->shard_first) * idx->lpr;
+    E.first = row_first; E.count = row_count; E.queries = s->d_queries; E.qpop = s->d_qpop;
+    E.req_all = s->d_req_all; E.out = s->d_out; E.world = (uint32_t)world; E.nq = nq; E.W = W;
+    *out = s;
+    return RADHIP_OK;
+}
+
+extern "C" uint32_t radhip_shard_width(const radhip_shard_t *s) { return s ? s->W : 0; }
+extern "C" uint64_t radhip_shard_state_bytes(const radhip_shard_t *s) { return s ? s->state_bytes : 0; }
+
+static int shard_check(radhip_shard *s) {
+    if (s->graph_gen != s->idx->graph_gen)
+        RH_FAIL(RADHIP_E_STATE, "the index changed since this sharded traversal was created: create a new one");
+    RH_HIP(hipSetDevice(s->idx->device));
+    return RADHIP_OK;
+}
+
+// enqueue one step kernel on the index's stream (no synchronisation)
+static int shard_enqueue_step(radhip_shard *s) {
+    RH_HIP(hipMemsetAsync(s->d_req + (size_t)s->nq * s->W, 0, 64, s->idx->stream));
+    hipLaunchKernelGGL(shard_step_kernel, dim3((s->nq + 63u) / 64u), dim3(64), 0, s->idx->stream, s->P);
+    RH_HIP(hipGetLastError());
+    return RADHIP_OK;
+}
+static int shard_enqueue_eval(radhip_shard *s) {
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->idx->device);
+    const uint64_t total = (uint64_t)s->world * s->nq * s->W;
+    const uint64_t per_block = 4ull * (64 / s->idx->lpr) * 4ull;
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((total + per_block - 1) / per_block, (uint64_t)n_cu * 8));
+    switch (s->idx->lpr) {
+        case 1: hipLaunchKernelGGL(shard_eval_kernel<1>, dim3(grid), dim3(256), 0, s->idx->stream, s->E); break;
+        case 2: hipLaunchKernelGGL(shard_eval_kernel<2>, dim3(grid), dim3(256), 0, s->idx->stream, s->E); break;
+        case 4: hipLaunchKernelGGL(shard_eval_kernel<4>, dim3(grid), dim3(256), 0, s->idx->stream, s->E); break;
+        case 8: hipLaunchKernelGGL(shard_eval_kernel<8>, dim3(grid), dim3(256), 0, s->idx->stream, s->E); break;
+        default: hipLaunchKernelGGL(shard_eval_kernel<16>, dim3(grid), dim3(256), 0, s->idx->stream, s->E); break;
+    }
+    RH_HIP(hipGetLastError());
+    return RADHIP_OK;
+}
+
+// ---- host-staged pieces (tests, rehearsal on one GPU, any exchange the host program has) -------------
+extern "C" int radhip_shard_step(radhip_shard_t *s, uint32_t *out_live) {
+    if (!s) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(s->idx->mu);
+    RH_TRY(shard_check(s));
+    RH_HIP(hipEventRecord(s->ev0, s->idx->stream));
+    RH_TRY(shard_enqueue_step(s));
+    RH_HIP(hipEventRecord(s->ev1, s->idx->stream));
+    uint32_t live = 0;
+    RH_HIP(hipMemcpyAsync(&live, s->d_req + (size_t)s->nq * s->W, 4, hipMemcpyDeviceToHost, s->idx->stream));
+    RH_HIP(hipStreamSynchronize(s->idx->stream));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->step_ms += ms;
+    s->steps++;
+    if (out_live) *out_live = live;
+    return RADHIP_OK;
+}
+extern "C" int radhip_shard_get_requests(radhip_shard_t *s, uint32_t *host) {
+    if (!s || !host) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(s->idx->mu);
+    RH_TRY(shard_check(s));
+    RH_HIP(hipMemcpy(host, s->d_req, (size_t)s->nq * s->W * 4, hipMemcpyDeviceToHost));
+    return RADHIP_OK;
+}
+extern "C" int radhip_shard_set_requests_all(radhip_shard_t *s, const uint32_t *host_all) {
+    if (!s || !host_all) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(s->idx->mu);
+    RH_TRY(shard_check(s));
+    const size_t per_rank = (size_t)s->nq * s->W;
+    for (int r = 0; r < s->world; ++r)
+        RH_HIP(hipMemcpy(s->d_req_all + (size_t)r * (per_rank + 16), host_all + (size_t)r * per_rank, per_rank * 4, hipMemcpyHostToDevice));
+    return RADHIP_OK;
+}
+extern "C" int radhip_shard_evaluate(radhip_shard_t *s) {
+    if (!s) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(s->idx->mu);
+    RH_TRY(shard_check(s));
+    RH_HIP(hipEventRecord(s->ev0, s->idx->stream));
+    RH_TRY(shard_enqueue_eval(s));
+    RH_HIP(hipEventRecord(s->ev1, s->idx->stream));
+    RH_HIP(hipStreamSynchronize(s->idx->stream));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->eval_ms += ms;
+    return RADHIP_OK;
+}
+extern "C" int radhip_shard_get_scores_out(radhip_shard_t *s, uint32_t *host) {
+    if (!s || !host) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(s->idx->mu);
+    RH_TRY(shard_check(s));
+    RH_HIP(hipMemcpy(host, s->d_out, (size_t)s->world * s->nq * s->W * 4, hipMemcpyDeviceToHost));
+    return RADHIP_OK;
+}
+extern "C" int radhip_shard_set_scores_in(radhip_shard_t *s, const uint32_t *host) {
+    if (!s || !host) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(s->idx->mu);
+    RH_TRY(shard_check(s));
+    RH_HIP(hipMemcpy(s->d_in, host, (size_t)s->nq * s->W * 4, hipMemcpyHostToDevice));
+    return RADHIP_OK;
+}
+
+// ---- the product loop: kernels and RCCL collectives on one stream, device buffers end to end ------------
+extern "C" int radhip_shard_run(radhip_shard_t *s, radhip_comm_t *comm, uint64_t max_steps, uint64_t *out_steps) {
+    if (!s || !comm) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (comm->world != s->world || comm->rank != s->rank) RH_FAIL(RADHIP_E_INVALID, "communicator and shard disagree on rank / world");
+    std::lock_guard<std::mutex> lk(s->idx->mu);
+    RH_TRY(shard_check(s));
+    hipStream_t st = s->idx->stream;
+    const size_t per_rank = (size_t)s->nq * s->W;
+    std::vector<uint32_t> live(s->world);
+    uint64_t steps = 0;
+    RH_HIP(hipEventRecord(s->ev0, st));
+    for (;;) {
+        RH_TRY(shard_enqueue_step(s));
+        RH_TRY(rh_comm_allgather_dev(comm, s->d_req, s->d_req_all, per_rank + 16, st));
+        RH_TRY(shard_enqueue_eval(s));
+        RH_TRY(rh_comm_reduce_scatter_u32_dev(comm, s->d_out, s->d_in, per_rank, st));
+        // the live counts of all ranks travel behind the candidates: every rank stops at the same step
+        for (int r = 0; r < s->world; ++r)
+            RH_HIP(hipMemcpyAsync(&live[r], s->d_req_all + (size_t)r * (per_rank + 16) + per_rank, 4, hipMemcpyDeviceToHost, st));
+        RH_HIP(hipStreamSynchronize(st));
+        steps++;
+        s->exchanged_bytes += (uint64_t)s->world * (per_rank + 16) * 4 + (uint64_t)s->world * per_rank * 4;
+        uint64_t tot = 0;
+        for (int r = 0; r < s->world; ++r) tot += live[r];
+        if (tot == 0 || (max_steps && steps >= max_steps)) break;
+    }
+    RH_HIP(hipEventRecord(s->ev1, st));
+    RH_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->step_ms += ms;
+    s->steps += steps;
+    if (out_steps) *out_steps = steps;
+    // a device-side failure of any local traversal is an error of the call
+    std::vector<ShardHeader> hdr(s->nq);
+    RH_HIP(hipMemcpy(hdr.data(), s->P.hdr, (size_t)s->nq * sizeof(ShardHeader), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < s->nq; ++i)
+        if (hdr[i].status < 0) RH_FAIL(hdr[i].status, "sharded traversal %u overflowed a fixed-capacity device structure (status %d)", i, hdr[i].status);
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_shard_stats(const radhip_shard_t *s, radhip_trav_stats_t *out) {
+    if (!s || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(s->idx->mu);
+    RH_HIP(hipSetDevice(s->idx->device));
+    std::vector<ShardHeader> hdr(s->nq);
+    RH_HIP(hipMemcpy(hdr.data(), s->P.hdr, (size_t)s->nq * sizeof(ShardHeader), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < s->nq; ++i) {
+        out[i].n_scored = hdr[i].n_scored; out[i].n_pops = hdr[i].n_pops; out[i].n_nbr = hdr[i].n_nbr;
+        out[i].n_repivot = 0; out[i].n_flush = 0; out[i].status = hdr[i].status; out[i].n_remid = 0;
+    }
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_shard_results(const radhip_shard_t *s, uint32_t q, uint32_t *out_slots, uint32_t *out_and,
+                                    uint32_t *out_or, uint64_t cap, uint64_t *out_n) {
+    if (!s || !out_n) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (q >= s->nq) RH_FAIL(RADHIP_E_RANGE, "traversal %u out of range", q);
+    std::lock_guard<std::mutex> lk(s->idx->mu);
+    RH_HIP(hipSetDevice(s->idx->device));
+    ShardHeader h;
+    RH_HIP(hipMemcpy(&h, s->P.hdr + q, sizeof h, hipMemcpyDeviceToHost));
+    *out_n = h.n_scored;
+    const uint64_t n = std::min<uint64_t>(h.n_scored, cap);
+    if (n == 0) return RADHIP_OK;
+    std::vector<uint2> buf(n);
+    RH_HIP(hipMemcpy(buf.data(), s->P.scored + (uint64_t)q * s->P.scored_cap, n * sizeof(uint2), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) {
+        if (out_slots) out_slots[i] = buf[i].x;
+        if (out_and) out_and[i] = buf[i].y & 0xFFFFu;
+        if (out_or) out_or[i] = buf[i].y >> 16;
+    }
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_shard_pop_log(const radhip_shard_t *s, uint32_t q, uint32_t *out_nodes, uint8_t *out_levels,
+                                    uint64_t cap, uint64_t *out_n) {
+    if (!s || !out_n) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (q >= s->nq) RH_FAIL(RADHIP_E_RANGE, "traversal %u out of range", q);
+    if (!s->P.poplog_nodes) RH_FAIL(RADHIP_E_STATE, "sharded traversal was created without RADHIP_TRAV_LOG_POPS");
+    std::lock_guard<std::mutex> lk(s->idx->mu);
+    RH_HIP(hipSetDevice(s->idx->device));
+    ShardHeader h;
+    RH_HIP(hipMemcpy(&h, s->P.hdr + q, sizeof h, hipMemcpyDeviceToHost));
+    const uint64_t m = std::min<uint64_t>(h.n_pops, s->P.poplog_cap);
+    *out_n = m;
+    const uint64_t n = std::min<uint64_t>(m, cap);
+    if (n == 0) return RADHIP_OK;
+    if (out_nodes) RH_HIP(hipMemcpy(out_nodes, s->P.poplog_nodes + (uint64_t)q * s->P.poplog_cap, n * 4, hipMemcpyDeviceToHost));
+    if (out_levels) RH_HIP(hipMemcpy(out_levels, s->P.poplog_levels + (uint64_t)q * s->P.poplog_cap, n, hipMemcpyDeviceToHost));
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_shard_timing(const radhip_shard_t *s, double *out_step_ms, double *out_eval_ms, uint64_t *out_steps,
+                                   uint64_t *out_exchanged_bytes) {
+    if (!s) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (out_step_ms) *out_step_ms = s->step_ms;
+    if (out_eval_ms) *out_eval_ms = s->eval_ms;
+    if (out_steps) *out_steps = s->steps;
+    if (out_exchanged_bytes) *out_exchanged_bytes = s->exchanged_bytes;
+    return RADHIP_OK;
+}

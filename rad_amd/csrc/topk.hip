@@ -209,6 +209,7 @@ extern "C" int radhip_tanimoto_topk(radhip_index_t *idx, const uint8_t *queries,
                                     uint32_t *out_or, uint32_t *out_counts) {
     if (!idx || !queries || !out_slots || !out_counts) RH_FAIL(RADHIP_E_INVALID, "null argument");
     if (!idx->has_vectors) RH_FAIL(RADHIP_E_STATE, "no vectors loaded");
+    RH_REQUIRE_FULL_CORPUS(idx);
     if (first + count > idx->n) RH_FAIL(RADHIP_E_RANGE, "rows [first, first+count) out of range");
     if (k == 0 || k > 1984) RH_FAIL(RADHIP_E_INVALID, "k must be in 1..1984 (got %u)", k);
     if (nq == 0) return RADHIP_OK;

@@ -749,6 +749,7 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     if (nq == 0) RH_FAIL(RADHIP_E_INVALID, "nq must be > 0");
     if (n_to_score == 0) RH_FAIL(RADHIP_E_INVALID, "n_to_score must be > 0");
     if (!idx->has_vectors || !idx->has_graph) RH_FAIL(RADHIP_E_STATE, "index needs vectors and a graph");
+    RH_REQUIRE_FULL_CORPUS(idx);
     if (idx->g_n > idx->n) RH_FAIL(RADHIP_E_STATE, "graph has more nodes (%llu) than the corpus has rows (%llu)",
                                    (unsigned long long)idx->g_n, (unsigned long long)idx->n);
     if (idx->g_n > 1000000000ull) RH_FAIL(RADHIP_E_INVALID, "RAD traversal needs slots < 1e9");

@@ -126,6 +126,10 @@ class DeviceIndex:
         check(self._L.radhip_index_read_layout(self._h, ptr(out)))
         return out
 
+    def keep_rows(self, first: int, count: int) -> None:
+        """Row-sharded multi-GPU mode: keep rows [first, first+count) of the corpus, free the rest."""
+        check(self._L.radhip_index_keep_rows(self._h, first, count))
+
     def traversal_capacity(self) -> int:
         """Traversals resident on the device at once (one wavefront each)."""
         n = C.c_uint32(0)
@@ -294,6 +298,92 @@ class DeviceTraversal:
         return "trav4_kernel" if int(self._L.radhip_traversal_kernel(self._h)) == 4 else "trav_kernel"
 
 
+class DeviceShard:
+    """One rank of the row-sharded traversal (radhip_shard_t): its rows of the corpus, the whole graph, its
+    nq traversals of the batch.  `queries_all` is [world * nq, row_bytes], rank-major, the same on every rank."""
+
+    def __init__(self, index: DeviceIndex, rank: int, world: int, row_first: int, row_count: int,
+                 queries_all: np.ndarray, n_to_score: int, log_pops: bool = False):
+        self._L = _lib.lib()
+        self.index = index
+        q = _lib.as_rows(queries_all, index.row_bytes, "queries_all")
+        if q.shape[0] % world:
+            raise ValueError("queries_all must hold world * nq rows")
+        self.rank, self.world, self.nq = int(rank), int(world), q.shape[0] // world
+        self._h = C.c_void_p()
+        check(self._L.radhip_shard_create(index._h, rank, world, row_first, row_count, ptr(q), self.nq, int(n_to_score),
+                                          _lib.TRAV_LOG_POPS if log_pops else 0, C.byref(self._h)))
+        self.width = int(self._L.radhip_shard_width(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.radhip_shard_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the product loop (RCCL on device buffers)
+    def run(self, comm: "RcclComm", max_steps: int = 0) -> int:
+        steps = C.c_uint64(0)
+        check(self._L.radhip_shard_run(self._h, comm._h, max_steps, C.byref(steps)))
+        return steps.value
+
+    # -- host-staged pieces (the `local` engine of rad_amd.sharded.RowShardedTraversal)
+    def step(self, scores_in: np.ndarray):
+        s = np.ascontiguousarray(scores_in, np.uint32).reshape(self.nq, self.width)
+        check(self._L.radhip_shard_set_scores_in(self._h, ptr(s)))
+        live = C.c_uint32(0)
+        check(self._L.radhip_shard_step(self._h, C.byref(live)))
+        req = np.empty((self.nq, self.width), np.uint32)
+        check(self._L.radhip_shard_get_requests(self._h, ptr(req)))
+        return req, live.value
+
+    def evaluate(self, requests_all: np.ndarray) -> np.ndarray:
+        r = np.ascontiguousarray(requests_all, np.uint32).reshape(self.world, self.nq, self.width)
+        check(self._L.radhip_shard_set_requests_all(self._h, ptr(r)))
+        check(self._L.radhip_shard_evaluate(self._h))
+        out = np.empty((self.world, self.nq, self.width), np.uint32)
+        check(self._L.radhip_shard_get_scores_out(self._h, ptr(out)))
+        return out
+
+    def stats(self) -> TraversalStats:
+        arr = (_lib.TravStats * self.nq)()
+        check(self._L.radhip_shard_stats(self._h, arr))
+        rec = np.frombuffer(arr, dtype=_TRAV_STATS_DTYPE, count=self.nq)
+        return TraversalStats(rec["n_scored"].astype(np.int64), rec["n_pops"].astype(np.int64),
+                              rec["n_nbr"].astype(np.int64), rec["status"].astype(np.int32))
+
+    def results(self, q: int):
+        n = C.c_uint64(0)
+        check(self._L.radhip_shard_results(self._h, q, None, None, None, 0, C.byref(n)))
+        k = n.value
+        s = np.empty(k, np.uint32); a = np.empty(k, np.uint32); o = np.empty(k, np.uint32)
+        check(self._L.radhip_shard_results(self._h, q, ptr(s), ptr(a), ptr(o), k, C.byref(n)))
+        return s, a, o
+
+    def pop_log(self, q: int):
+        n = C.c_uint64(0)
+        check(self._L.radhip_shard_pop_log(self._h, q, None, None, 0, C.byref(n)))
+        k = n.value
+        nodes = np.empty(k, np.uint32); levels = np.empty(k, np.uint8)
+        check(self._L.radhip_shard_pop_log(self._h, q, ptr(nodes), ptr(levels), k, C.byref(n)))
+        return nodes, levels
+
+    def timing(self):
+        """(step-kernel ms [whole loop ms after run()], evaluation-kernel ms, steps, exchanged bytes)"""
+        a, b = C.c_double(0), C.c_double(0)
+        n, x = C.c_uint64(0), C.c_uint64(0)
+        check(self._L.radhip_shard_timing(self._h, C.byref(a), C.byref(b), C.byref(n), C.byref(x)))
+        return a.value, b.value, n.value, x.value
+
+    def state_bytes(self) -> int:
+        return int(self._L.radhip_shard_state_bytes(self._h))
+
+
 class RcclComm:
     """RCCL communicator of the C ABI (one process per GPU).  `unique_id()` is called on rank 0;
     the 128 bytes reach the other ranks through whatever channel the host program has."""
@@ -330,4 +420,4 @@ class RcclComm:
             pass
 
 
-__all__ = ["RcclComm", "DeviceIndex", "DeviceTraversal", "TraversalStats", "distance_f32", "NO_SLOT", "RadHipError"]
+__all__ = ["RcclComm", "DeviceShard", "DeviceIndex", "DeviceTraversal", "TraversalStats", "distance_f32", "NO_SLOT", "RadHipError"]

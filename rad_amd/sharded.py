@@ -1,23 +1,29 @@
-"""Corpus-sharded RAD traversal: one shard (rows + shard-local layered graph) per GPU, one
-process per GPU, a per-round RCCL all-gather of frontier candidate scores and scored counts.
+"""Multi-GPU traversal: one process per GPU.
 
-Semantics ("federated best-first", this build's definition — the reference has no multi-GPU
-path).  A query's traversal runs on every shard against that shard's graph.  A global budget
-`n_to_score` is split over the shards round by round:
+`RowShardedTraversal` — the mode BASELINE.json's north_star and SURVEY.md §8(e) describe.  The
+fingerprint corpus is partitioned by contiguous slot range, the layered graph is ONE graph over all
+rows, the traversals of a batch are partitioned over the ranks.  Per frontier step:
 
-    round:    every shard advances each of its traversals until it has scored its current
-              target (or its queue is empty), at most `round_pops` expansions if given
-    exchange: all-gather {scored count, best frontier key} of every traversal (2 x u64 each)
-    every rank computes the same new targets with `allocate_targets`:
-              remaining = n_to_score - sum(scored); shards whose queue is empty (or whose
-              local capacity is used up) get nothing; the others split `remaining` evenly,
-              the remainder going to the shards with the best (smallest) frontier key first,
-              ties by rank
-    stop:     remaining <= 0, or no shard can take more, or a round made no progress
+    step      every rank advances each of ITS traversals to the point where a fingerprint would be
+              read: apply the scores of the last step's candidates (scored insert + queue insert,
+              rad/coordination_service.py:379-389), pop / expand (visited test-and-set,
+              rad/visited.py:17-29) until a neighbour is not in the scored set
+              (rad/distributed_worker.py:296-305); those slots are the frontier candidates
+    exchange  all-gather of the candidates of all ranks (nq x W slots each, RADHIP_NO_SLOT padded)
+    evaluate  every rank scores the candidates whose rows it owns against the asking traversal's query
+    exchange  the packed (and | or << 16) scores return to the asking rank: a reduce-scatter of
+              disjoint contributions (a candidate has one owner; everybody else adds 0)
 
-With one shard it degenerates to the single-GPU traversal (target = n_to_score).  The result
-of a query is the union of the shards' scored lists (slots are shard-local; global slot =
-shard row offset + slot).
+The control flow per traversal is the single-GPU one (strict best-first), so scored lists and pop logs
+are bit-identical to a single-GPU traversal of the same corpus and graph for any number of ranks:
+tests/test_sharded.py (world 2, gloo, the oracle's stepper as the local engine) and
+tests/test_gpu_sharded.py (two ranks' worth of kernels on one GPU).  On GPUs the whole loop runs in
+the library (radhip_shard_run: kernels and RCCL collectives on one stream, device buffers);
+`RowShardedTraversal` is the same loop with the exchange injected, for hosts that own the exchange.
+
+`FederatedTraversal` (the round-1 mode, kept as a labelled alternative): shard-LOCAL graphs and a
+global budget split round by round — cheaper to exchange (16 B per traversal and round) but NOT the
+traversal of one global graph; its results cannot be compared with a single-GPU run.
 """
 from __future__ import annotations
 
@@ -26,6 +32,41 @@ from typing import Callable, Tuple
 import numpy as np
 
 KEY_EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
+NO_SLOT = np.uint32(0xFFFFFFFF)
+
+
+class RowShardedTraversal:
+    """Drives one rank of the row-sharded traversal with an injected exchange.
+
+    `local` provides  nq, width,
+        step(scores_in u32[nq, W]) -> (requests u32[nq, W], live)      advance the local traversals
+        evaluate(requests_all u32[world, nq, W]) -> u32[world, nq, W]  score the candidates this rank owns
+    (rad_amd.device.DeviceShard on a GPU; the oracle's stepper in the CPU tests).
+    `allgather(u32[...]) -> u32[world, ...]`, `reduce_scatter(u32[world, ...]) -> u32[...]` (sum over
+    ranks of this rank's block) are the exchange: gloo in the CPU tests, rad_amd.rendezvous.TcpGroup when
+    several ranks rehearse on one GPU."""
+
+    def __init__(self, local, allgather: Callable, reduce_scatter: Callable, rank: int, world: int):
+        self.local, self.allgather, self.reduce_scatter = local, allgather, reduce_scatter
+        self.rank, self.world = int(rank), int(world)
+        self.steps = 0
+        self.exchanged_bytes = 0
+
+    def run(self, max_steps: int = 0) -> int:
+        nq, W = self.local.nq, self.local.width
+        scores = np.zeros((nq, W), np.uint32)
+        while True:
+            req, live = self.local.step(scores)
+            # the live count travels behind the candidates: every rank sees the same total and stops at the same step
+            send = np.concatenate([np.ascontiguousarray(req, np.uint32).reshape(-1), np.array([live], np.uint32)])
+            allv = np.asarray(self.allgather(send), np.uint32).reshape(self.world, nq * W + 1)
+            self.steps += 1
+            self.exchanged_bytes += allv.nbytes
+            if int(allv[:, -1].astype(np.int64).sum()) == 0 or (max_steps and self.steps >= max_steps):
+                return self.steps
+            out = np.asarray(self.local.evaluate(allv[:, :-1].reshape(self.world, nq, W)), np.uint32)
+            scores = np.asarray(self.reduce_scatter(out.reshape(self.world, nq, W)), np.uint32).reshape(nq, W)
+            self.exchanged_bytes += out.nbytes
 
 
 def allocate_targets(scored: np.ndarray, frontier: np.ndarray, n_to_score: int,
@@ -54,8 +95,9 @@ def allocate_targets(scored: np.ndarray, frontier: np.ndarray, n_to_score: int,
     return targets.astype(np.uint64), done
 
 
-class ShardedTraversal:
-    """Drives one shard's traversal object through the federated rounds.
+class FederatedTraversal:
+    """LABELLED ALTERNATIVE (not the north-star partitioning): drives one shard's traversal object through
+    the federated rounds over shard-local graphs.
 
     `local` needs nq, set_targets(u64[nq]), run(max_pops) and frontier() -> (keys, scored):
     rad_amd.device.DeviceTraversal on a GPU.  `allgather(u64[k]) -> u64[world, k]` is the
@@ -98,3 +140,6 @@ class ShardedTraversal:
                 return sc, fr
             prev_total = total
             self.local.set_targets(targets[self.rank])
+
+
+ShardedTraversal = FederatedTraversal   # round-1 name

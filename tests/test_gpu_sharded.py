@@ -111,3 +111,103 @@ def test_rccl_comm_world1(gpu):
     out = c.allgather_u64(a)
     assert out.shape == (1, 1000) and np.array_equal(out[0], a)
     c.close()
+
+
+# ------------------------------------------------------------------ row-sharded traversal (north star)
+def _lockstep(shards):
+    """The per-step exchange of rad_amd.sharded.RowShardedTraversal for ranks that live in one process:
+    all-gather = stack, reduce-scatter = sum over ranks of the block of each rank."""
+    world = len(shards)
+    scores = [np.zeros((s.nq, s.width), np.uint32) for s in shards]
+    steps = 0
+    while True:
+        stepped = [s.step(scores[r]) for r, s in enumerate(shards)]
+        steps += 1
+        if sum(live for _req, live in stepped) == 0:
+            return steps
+        req_all = np.stack([req for req, _live in stepped])
+        outs = [s.evaluate(req_all) for s in shards]
+        scores = [sum(outs[k][r] for k in range(world)) for r in range(world)]
+
+
+def _row_sharded_setup(oracle, n, nts, world, nq, mode=2, seed=7):
+    X = oracle.synth_rows(0, n, n, 1024, seed, mode)
+    idx_rows = []
+    from rad_amd.device import DeviceIndex
+    full = DeviceIndex(1024, 8, 16, 48)
+    full.add_rows(X, seed=3, max_batch=256)                 # ONE graph over all rows, built on the GPU
+    levels, adj0, upper_row, adjU = full.read_graph()
+    inf = full.info()
+    g = oracle.Graph(n, 16, 8, int(inf.max_level), int(inf.entry), levels, adj0, upper_row, adjU)
+    Qall = X[np.random.default_rng(seed).integers(0, n, world * nq)].copy()
+    return X, g, full, Qall
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_equals_single_gpu_traversal(gpu, oracle, world):
+    """`world` ranks' worth of step / evaluation kernels on one GPU, each rank keeping ONLY its rows
+    (radhip_index_keep_rows): every query's scored order, counts and pop log equal the oracle's traversal of
+    the whole corpus, and the single-GPU kernel's."""
+    from rad_amd.device import DeviceIndex, DeviceShard, DeviceTraversal
+    n, nts, nq = 20000, 1500, 5
+    X, g, full, Qall = _row_sharded_setup(oracle, n, nts, world, nq)
+    single = DeviceTraversal(full, Qall, nts, log_pops=True)
+    assert single.run() == 0
+    levels, adj0, upper_row, adjU = g.levels, g.adj0, g.upper_row, g.adjU
+    shards, idxs = [], []
+    rows = n // world
+    for r in range(world):
+        first = r * rows
+        count = rows if r < world - 1 else n - first
+        idx = DeviceIndex(1024, 8, 16, 48)
+        idx.load_vectors(X)
+        idx.load_graph(levels, adj0, upper_row, adjU, g.max_level, g.entry)
+        idx.keep_rows(first, count)                          # this rank holds its rows only
+        assert idx.info().has_vectors
+        idxs.append(idx)
+        shards.append(DeviceShard(idx, r, world, first, count, Qall, nts, log_pops=True))
+    steps = _lockstep(shards)
+    assert steps > 10
+    for r in range(world):
+        st = shards[r].stats()
+        assert set(st.status.tolist()) <= {1, 2}
+        for q in range(nq):
+            t = r * nq + q
+            want = oracle.rad_traverse(g, X, Qall[t], nts)
+            s, a, o = shards[r].results(q)
+            nodes, lv = shards[r].pop_log(q)
+            assert np.array_equal(s, want.slots), (r, q)
+            assert np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt)
+            assert np.array_equal(nodes, want.pop_nodes) and np.array_equal(lv, want.pop_levels)
+            s1, a1, o1 = single.results(t)
+            assert np.array_equal(s, s1) and np.array_equal(a, a1) and np.array_equal(o, o1)
+            assert st.n_pops[q] == want.n_pops and st.n_nbr[q] == want.n_nbr
+
+
+def test_row_sharded_native_loop_world1_rccl(gpu, oracle):
+    """radhip_shard_run — the product loop (kernels + RCCL collectives on one stream, device buffers) — with
+    a real RCCL communicator of world 1, to a drained queue (n_to_score = n)."""
+    from rad_amd.device import DeviceShard, RcclComm
+    n, nq = 3000, 4
+    X, g, full, Qall = _row_sharded_setup(oracle, n, n, 1, nq, mode=1, seed=4)
+    comm = RcclComm(0, 1, RcclComm.unique_id(), 0)
+    sh = DeviceShard(full, 0, 1, 0, n, Qall, n, log_pops=True)
+    steps = sh.run(comm)
+    assert steps > 10
+    for q in range(nq):
+        want = oracle.rad_traverse(g, X, Qall[q], n)
+        s, a, o = sh.results(q)
+        assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt)
+    step_ms, eval_ms, nsteps, xbytes = sh.timing()
+    assert nsteps == steps and xbytes > 0 and step_ms > 0
+
+
+def test_sharded_index_refuses_whole_corpus_entry_points(gpu, oracle):
+    from rad_amd._lib import RadHipError
+    from rad_amd.device import DeviceTraversal
+    X, g, full, Qall = _row_sharded_setup(oracle, 2000, 100, 2, 1)
+    full.keep_rows(1000, 1000)
+    for call in (lambda: full.scan(Qall[:1]), lambda: DeviceTraversal(full, Qall[:1], 10), lambda: full.read_vectors(0, 1),
+                 lambda: full.keep_rows(0, 10)):
+        with pytest.raises(RadHipError):
+            call()

@@ -1,6 +1,10 @@
-"""Multi-GPU path on CPU: the federated-rounds logic of rad_amd/sharded.py with world_size 2
-over torch.distributed (gloo), the oracle standing in for the device traversal; plus the pure
-allocation function."""
+"""Multi-GPU paths on CPU, world_size 2 over torch.distributed (gloo), the oracle standing in for the
+device kernels:
+  * the row-sharded traversal (ONE global graph, rows and traversals partitioned, per-step exchange of
+    frontier candidates and their scores): the result of every query must EQUAL the single-process oracle
+    traversal of the same global corpus and graph — scored order, counts and pop log;
+  * the plain-TCP process group the bench uses instead of torch (rad_amd/rendezvous.py);
+  * the federated rounds (labelled alternative) and their allocation function."""
 import os
 import socket
 import sys
@@ -114,3 +118,102 @@ def test_sharded_traversal_world2_gloo(tmp_path, oracle):
         for r, l in enumerate(locals_):
             l.set_targets(t[r])
     assert rounds == int(r0["rounds"]) and np.array_equal(scm.astype(np.int64), sc)
+
+
+# ------------------------------------------------------------------ row-sharded traversal (north star)
+def _row_worker(rank, world, port, out_path, exchange):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import rad_oracle as O
+    from rad_amd.sharded import RowShardedTraversal
+    from sharded_util import OracleRowShard
+    n, ndim, M, cap0, nts, nq = 9000, 1024, 8, 16, 1200, 3
+    X = O.synth_rows(0, n, n, ndim, 5, 2)
+    g = O.synth_graph(n, M, cap0, 21)
+    Qall = X[[11, 4000, 8999, 17, 5555, 2]].copy()            # world * nq queries, rank-major
+    rows = n // world
+    first = rank * rows
+    count = rows if rank < world - 1 else n - first
+    local = OracleRowShard(O, g, X[first:first + count], first, Qall, rank, world, nts)
+    if exchange == "gloo":
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+
+        def allgather(a):
+            t = torch.from_numpy(np.ascontiguousarray(a, np.uint32).view(np.int32))
+            outs = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(outs, t)
+            return np.stack([o.numpy().view(np.uint32) for o in outs])
+
+        def reduce_scatter(a):       # gloo has no reduce_scatter: all-reduce, keep this rank's block
+            t = torch.from_numpy(np.ascontiguousarray(a, np.uint32).view(np.int32).copy())
+            dist.all_reduce(t)
+            return t.numpy().view(np.uint32)[rank]
+        finish = lambda: (dist.barrier(), dist.destroy_process_group())
+    else:
+        from rad_amd.rendezvous import TcpGroup
+        grp = TcpGroup(rank, world, "127.0.0.1", port)
+        assert grp.broadcast_obj(b"id" if rank == 0 else None) == b"id"
+        assert grp.allreduce([rank + 1.0, 2.0], "max").tolist() == [float(world), 2.0]
+        allgather, reduce_scatter = grp.allgather_u32, grp.reduce_scatter_sum_u32
+        finish = lambda: (grp.barrier(), grp.close())
+    drv = RowShardedTraversal(local, allgather, reduce_scatter, rank, world)
+    steps = drv.run()
+    res = {}
+    for q in range(nq):
+        s, a, o, pn, pl = local.results(q)
+        res.update({f"s{q}": s, f"a{q}": a, f"o{q}": o, f"pn{q}": pn, f"pl{q}": pl})
+    np.savez(out_path, steps=steps, bytes=drv.exchanged_bytes, **res)
+    finish()
+
+
+@pytest.mark.parametrize("exchange", ["gloo", "tcp"])
+def test_row_sharded_traversal_equals_single_index_world2(tmp_path, oracle, exchange):
+    import multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world, nq = 2, 3
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_row_worker, args=(r, world, port, str(tmp_path / f"row{r}.npz"), exchange)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    n, nts = 9000, 1200
+    X = oracle.synth_rows(0, n, n, 1024, 5, 2)
+    g = oracle.synth_graph(n, 8, 16, 21)
+    Qall = X[[11, 4000, 8999, 17, 5555, 2]]
+    outs = [np.load(tmp_path / f"row{r}.npz") for r in range(world)]
+    assert int(outs[0]["steps"]) == int(outs[1]["steps"]) > 10          # every rank stopped at the same step
+    for r in range(world):
+        for q in range(nq):
+            want = oracle.rad_traverse(g, X, Qall[r * nq + q], nts)      # single index, whole corpus
+            z = outs[r]
+            assert np.array_equal(z[f"s{q}"], want.slots), (r, q)
+            assert np.array_equal(z[f"a{q}"], want.and_cnt) and np.array_equal(z[f"o{q}"], want.or_cnt)
+            assert np.array_equal(z[f"pn{q}"], want.pop_nodes) and np.array_equal(z[f"pl{q}"], want.pop_levels)
+
+
+def test_stepper_equals_sequential_traversal(oracle):
+    """the oracle's stepper (what the sharded step kernel restates), driven with a local evaluator, IS the
+    sequential traversal: same scored order, counts, pop log — including a drained queue"""
+    n = 4000
+    X = oracle.synth_rows(0, n, n, 1024, 3, 2)
+    g = oracle.synth_graph(n, 8, 16, 5)
+    for qi, nts in ((7, 600), (100, n), (3999, 1)):
+        want = oracle.rad_traverse(g, X, X[qi], nts)
+        st = oracle.Stepper(g, nts)
+        a = o = None
+        while True:
+            req = st.step(a, o)
+            if req.size == 0:
+                break
+            a, o = oracle.gather(X, X[qi], req)
+        r = st.result()
+        assert np.array_equal(r.slots, want.slots) and np.array_equal(r.and_cnt, want.and_cnt) and np.array_equal(r.or_cnt, want.or_cnt)
+        assert np.array_equal(r.pop_nodes, want.pop_nodes) and np.array_equal(r.pop_levels, want.pop_levels)
+        assert st.status == (1 if len(want.slots) >= nts else 2)

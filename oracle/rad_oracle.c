@@ -106,10 +106,22 @@ typedef struct {
     uint8_t level;
 } pq_item_t;
 
+/* "{node_id}:{level}" written out by hand (what snprintf("%u:%d") produces; levels are 0..15) */
+static int member_str(char *m, uint32_t s, int l) {
+    char d[12];
+    int k = 0, n = 0;
+    do { d[k++] = (char)('0' + s % 10u); s /= 10u; } while (s);
+    while (k) m[n++] = d[--k];
+    m[n++] = ':';
+    if (l >= 10) m[n++] = (char)('0' + l / 10);
+    m[n++] = (char)('0' + l % 10);
+    m[n] = 0;
+    return n;
+}
 static int member_cmp(uint32_t sa, int la, uint32_t sb, int lb) {
     char ma[32], mb[32];
-    snprintf(ma, sizeof ma, "%u:%d", sa, la);
-    snprintf(mb, sizeof mb, "%u:%d", sb, lb);
+    member_str(ma, sa, la);
+    member_str(mb, sb, lb);
     return strcmp(ma, mb); /* ASCII: identical to bytewise compare */
 }
 
@@ -290,6 +302,12 @@ int orc_rad_traverse(const orc_graph_t *g, const uint8_t *corpus,
         uint32_t cap = 0;
         const uint32_t *row = graph_row(g, cur.slot, cur.level, &cap);
         if (!row) { rc = -3; goto done; }
+        /* the rows the loop below may read: software prefetch, as a tuned CPU implementation would */
+        for (uint32_t j = 0; j < cap && row[j] != ORC_NO_SLOT; ++j) {
+            const uint8_t *r_ = corpus + (uint64_t)row[j] * row_bytes;
+            __builtin_prefetch(r_);
+            if (row_bytes > 64) __builtin_prefetch(r_ + 64);
+        }
         /* submit_work_results :369-389 (scores computed in
          * distributed_worker.py:296-305 only for nodes not yet scored) */
         for (uint32_t j = 0; j < cap && row[j] != ORC_NO_SLOT; ++j) {

@@ -18,6 +18,19 @@ _SO = os.path.join(_HERE, "_build", "librad_oracle.so")
 NO_SLOT = 0xFFFFFFFF
 
 
+def build_native() -> str:
+    """-O3 -march=native build for THIS host (the cpu_baseline leg of bench.py times it); the portable
+    build stays what the parity tests load."""
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"])
+    return os.path.join(_HERE, "_build", "librad_oracle_native.so")
+
+
+def use_library(path: str) -> None:
+    """Point the wrapper at another build of the same source (before the first call)."""
+    global _SO, _lib
+    _SO, _lib = path, None
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "rad_oracle.c")
     hdr = os.path.join(_HERE, "rad_oracle.h")
@@ -49,7 +62,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if _SO.endswith("librad_oracle.so"):
+            build()
         L = C.CDLL(_SO)
         L.orc_distance_f32.restype = C.c_float
         L.orc_distance_f32.argtypes = [C.c_uint32, C.c_uint32]

@@ -1,5 +1,6 @@
-"""bench.py prints ONE JSON line with the driver's contract fields plus `roofline` and `cpu_baseline`
-(small workload here; the full-size line is the driver's)."""
+"""bench.py prints ONE JSON line with the driver's contract fields plus `roofline`, `cpu_baseline` and the
+parity sample (small workload here; the full-size line is the driver's) — and `--gpus 2` from a bare
+invocation really runs two ranks (both on GPU 0 here, host-staged exchange) and reports both N > 1 modes."""
 import json
 import os
 import subprocess
@@ -11,24 +12,55 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_json_contract(gpu):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                          "--rows", "300000", "--nq", "1024", "--n-to-score", "3000", "--cpu-traversals", "16"],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
+def _run(*flags, timeout=900):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "exactly one line on stdout"
-    j = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def _contract(j, n_gpus, steps):
     for k, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                    ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
-                   ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+                   ("config", dict), ("roofline", dict)):
         assert isinstance(j[k], typ), (k, j[k])
-    assert j["vs_baseline"] is None and j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1
+    assert j["vs_baseline"] is None and j["n_gpus"] == n_gpus and j["steps"] == steps and j["warmup"] == 1
     assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["data"] == "synthetic" and j["value"] > 0
     assert "workload" in j["config"] and "model" not in j["config"]
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0 and "traffic" in r
-    assert r["kernel"] in ("trav_kernel", "trav4_kernel") and r["launches"] == 2 and r["avg_launch_ms"] > 0
+    assert r["kernel"] in ("trav_kernel", "trav4_kernel") and r["launches"] == steps and r["avg_launch_ms"] > 0
+    assert r["launch_ms_p10"] <= r["launch_ms_median"] <= r["launch_ms_p90"]
+
+
+def test_bench_json_contract(gpu):
+    j = _run("--gpus", "1", "--steps", "2", "--warmup", "1", "--rows", "300000", "--nq", "1024", "--n-to-score", "3000",
+             "--cpu-seconds", "1")
+    _contract(j, 1, 2)
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == j["unit"] and c["sample"]
+    assert c["one_thread_value"] > 0 and c["cpu_model"]
+    done, total = j["parity_sample"].split("/")
+    assert done == total and int(total) > 0                      # the oracle's sample equals the GPU's counters
+    assert j["config"]["corpus_mode"] == 2 and j["config"]["graph_recall_at_10_ef128"] > 0.5
+    ref = j["reference_corpus_r01"]
+    assert ref["value"] > 0 and 0 < ref["roofline_frac"] < 1
+
+
+def test_bench_two_ranks_from_a_bare_invocation(gpu):
+    """no launcher: bench.py spawns its ranks itself; two ranks share GPU 0, so the exchange is host-staged"""
+    j = _run("--gpus", "2", "--steps", "1", "--warmup", "1", "--rows", "200000", "--nq", "512", "--n-to-score", "1500",
+             "--sharded-nq", "64", "--exchange", "host", "--single-device")
+    _contract(j, 2, 1)
+    sh, rp = j["sharded"], j["replicas"]
+    assert j["value"] == sh["value"] > 0 and rp["value"] > 0
+    done, total = sh["parity_vs_single_gpu"].split("/")
+    assert done == total == str(2 * 64)
+    assert sh["frontier_steps_per_step"] > 10 and sh["exchanged_bytes_per_rank_per_step"] > 0
+    assert "row-sharded" in j["config"]["parallelism"] and "host-staged" in sh["exchange"]
+    j2 = _run("--gpus", "2", "--steps", "1", "--warmup", "1", "--rows", "200000", "--nq", "512", "--n-to-score", "1500",
+              "--sharded-nq", "64", "--exchange", "host", "--single-device", "--mode", "replicas")
+    assert j2["value"] == j2["replicas"]["value"] and "replicas" in j2["config"]["parallelism"]

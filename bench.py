@@ -66,8 +66,8 @@ def parse_args():
                          "generator (corpus mode 1 only; set up in 20 ms)")
     ap.add_argument("--expansion-add", type=int, default=64, help="expansion_add of the built graph")
     ap.add_argument("--table", choices=["auto", "hash", "group"], default="auto",
-                    help="visited/scored table of the traversal kernel (auto: the library's choice from the layout statistics)")
-    ap.add_argument("--no-layout", action="store_true", help="do not compute the graph-locality layout")
+                    help="visited/scored table of the traversal kernel (auto = the library's default, the per-slot hash table; "
+                         "group = the grouped table over the graph-locality layout, measured slower: profiles/r02)")
     ap.add_argument("--no-reference-corpus", action="store_true", help="skip the round-1 corpus leg (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work the cpu_baseline sample should take at least")
@@ -157,7 +157,7 @@ def build_index(args, mode, device, layout=True):
         t_build = time.perf_counter() - t_build
         del X
     info = None
-    if layout and not args.no_layout:
+    if layout and args.table == "group":
         info = idx.optimize_layout()
     return idx, t_build, info
 

@@ -260,10 +260,10 @@ int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t *out);
  * (batches larger than two resident rounds of the one-per-wavefront kernel, rows <= 16 wide), 1 = one per
  * wavefront with speculative fingerprint gathers (small batches, wide rows).  Same results. */
 int radhip_traversal_kernel(const radhip_traversal_t *t);
-/* Which visited/scored table the object uses: 1 = grouped (2 bits per node in 16-B chunks of 48 layout ids,
- * 8 chunks to a 128-B line; chosen when the index has a graph-locality layout whose adjacency rows span
- * clearly fewer groups than they have neighbours), 0 = one hash entry per node.  RADHIP_TABLE=group|hash
- * in the environment forces one.  Same results. */
+/* Which visited/scored table the object uses: 0 = one hash entry per node (the default), 1 = grouped (2 bits
+ * per node in 16-B chunks of 48 layout ids, 8 chunks to a 128-B line; opt-in with RADHIP_TABLE=group in the
+ * environment, needs radhip_index_optimize_layout — fewer HBM lines per expansion, measured slower end to end
+ * on the round-2 workloads, see profiles/r02).  Same results. */
 int radhip_traversal_table(const radhip_traversal_t *t);
 
 /* per-traversal stop targets (each clamped to n_to_score): a traversal parks (status 3) once

@@ -806,15 +806,17 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     P.ht_log2 = ht_log2; P.ut_log2 = ut_log2; P.scored_cap = scored_cap; P.pq_cap = pq_cap;
     t->ht_log2 = ht_log2;
     t->graph_gen = idx->graph_gen;
-    {   // Grouped table: when the index carries a graph-locality layout whose rows span clearly fewer groups
-        // than they have neighbours (RADHIP_TABLE=group|hash forces one).  8 chunks per line, one chunk per
-        // scored node in the worst case, at most 80 % of the chunk slots used.
+    {   // Grouped table (RADHIP_TABLE=group; needs the index's graph-locality layout).  It cuts the table lines of an
+        // expansion from one per neighbour to one per group the neighbours span (3.4 instead of 9.9 on the bench
+        // graph), but the bench kernel is not bound by lines on graphs that have such locality (few new nodes per
+        // expansion: latency-bound), and graphs whose expansions ARE line-bound (round 1's corpus) have no locality to
+        // group by: measured 2-5 % slower than the per-slot table on every workload of profiles/r02, so the library
+        // never picks it by itself.  8 chunks per line, one chunk per scored node in the worst case, <= 80 % load.
         const char *e = getenv("RADHIP_TABLE");
-        const bool force_hash = e && e[0] == 'h', force_group = e && e[0] == 'g';
+        const bool force_group = e && e[0] == 'g';
         const uint32_t gt_log2 = std::max<uint32_t>(7, log2_ceil((scored_cap * 5 + 31) / 32));
         const bool can = idx->layout_valid && idx->d_adjx0 && t->use4 && gt_log2 <= 17;
-        const bool pays = idx->layout_lines_per_row <= 0.75 * idx->layout_degree;
-        t->use_gt = can && !force_hash && (pays || force_group);
+        t->use_gt = can && force_group;
         P.gt_log2 = gt_log2;
         P.adjx0 = idx->d_adjx0; P.adjxU = idx->d_adjxU; P.topx = idx->d_topx; P.lid = idx->d_lid;
     }

@@ -142,6 +142,28 @@ def run_reference(g, scoring_fn, n_to_score, namespace):
                 best10=[[int(i), float(s), smi] for i, s, smi in best])
 
 
+def run_reference_tolerant(g, scoring_fn, n_to_score, namespace, max_items=100000):
+    """run_reference without the assertion: records whether the reference's worker completed each item.
+    A work item whose neighbour list is empty is FAILED by the reference (rad/distributed_worker.py:286-288):
+    nothing is submitted, so the node is neither expanded nor descended; the item stays assigned until the
+    coordinator's 120 s cleanup re-queues it (rad/coordination_service.py:554-580), which a sequential drive
+    never reaches."""
+    trav = RADTraverser(hnsw_service=ToyService(g), scoring_fn=scoring_fn, redis_host="fake", namespace=namespace)
+    trav.prime()
+    cs = trav.coordination_service
+    cs.register_worker("w0")
+    worker = DistributedWorker(worker_id="w0", coordination_service=cs, scoring_fn=scoring_fn)
+    pops, oks = [], []
+    while len(cs.scored_set) < n_to_score and len(pops) < max_items:
+        item = cs.request_work("w0")
+        if item is None:
+            break
+        pops.append([int(item.node_id), int(item.level), float(item.score)])
+        oks.append(bool(worker._process_work_item(item)))
+    mols = trav.get_molecules()
+    return dict(pops=pops, ok=oks, molecules=[[int(i), float(s), smi] for i, s, smi in mols])
+
+
 def hash_score(smiles):
     """Deterministic pseudo docking score from the smiles string (lower = better)."""
     h = 1469598103934665603
@@ -169,6 +191,18 @@ def main():
     out["g1_all"] = dict(n_to_score=10 ** 9, n_pops=len(res_all["pops"]), n_scored=len(res_all["molecules"]),
                          pops_head=res_all["pops"][:50], pops_tail=res_all["pops"][-50:],
                          molecules_tail=res_all["molecules"][-50:])
+
+    # ---------------- G7: an EMPTY adjacency row (the stated deviation) --------------
+    # the first node the G1 traversal expands on an upper level loses its row on that level
+    first_upper = next(p for p in res_all["pops"] if p[1] >= 1)
+    v, lv = int(first_upper[0]), int(first_upper[1])
+    g7 = {k: (np.array(val, copy=True) if isinstance(val, np.ndarray) else val) for k, val in g.items()}
+    g7["adjU"][int(g7["upper_row"][v]) + lv - 1, :] = NO_SLOT
+    r7 = run_reference_tolerant(g7, hash_score, 10 ** 9, "g7")
+    save_graph_npz(os.path.join(HERE, "g7_graph.npz"), fps, g7, {})
+    out["g7"] = dict(emptied_node=v, emptied_level=lv, n_pops=len(r7["pops"]), n_scored=len(r7["molecules"]),
+                     pops=r7["pops"], ok=r7["ok"], failed_items=[r7["pops"][i] for i, k in enumerate(r7["ok"]) if not k],
+                     molecules=r7["molecules"])
 
     # ---------------- G1t: Tanimoto-scored traversals (A1 + A5-A10) ----------------
     for tag, ndim, n, M, cap0, nts_list in (("t64", 64, 500, 4, 8, (60, 300, 10 ** 9)),

@@ -179,6 +179,32 @@ def test_traverser_reproduces_reference_traversal_hash_scores():
     assert stats["coordination"]["pending_work"] == 0
 
 
+def test_empty_adjacency_row_the_stated_deviation():
+    """Golden G7: the first node the G1 traversal expands above level 0 has lost its row on that level.  The
+    REFERENCE fails that work item (rad/distributed_worker.py:286-288: recorded ok = False) — nothing is
+    submitted, the node does not descend from it, and the item stays assigned until the coordinator's 120 s
+    cleanup.  This build completes the item and descends (deviation 1): the node appears one
+    level down right away instead of whenever another path reaches it.  Everything before the empty row is
+    identical, and on this graph both end with the same scored set."""
+    from rad_amd.priority_queue import InProcessPQ
+    from rad_amd.traverser import RADTraverser
+    g = golden()["g7"]
+    z = load_graph_npz("g7_graph.npz")
+    v, lv = g["emptied_node"], g["emptied_level"]
+    assert (z["adjU"][z["upper_row"][v] + lv - 1] == NO_SLOT).all()
+    assert g["failed_items"] == [[v, lv, g["pops"][g["ok"].index(False)][2]]] and g["ok"].count(False) == 1
+    pq = _PopLogPQ(InProcessPQ())
+    t = RADTraverser(hnsw_service=_toy_service(z), scoring_fn=_hash_score, priority_queue=pq)
+    t.prime()
+    t.traverse(n_workers=1, n_to_score=10 ** 9)
+    at = g["ok"].index(False)
+    assert pq.log[:at + 1] == g["pops"][:at + 1]                      # identical up to and including the empty row
+    assert pq.log[at + 1] == [v, lv - 1, g["pops"][at][2]]            # ours descends at once, same score
+    assert g["pops"][at + 1] != [v, lv - 1, g["pops"][at][2]]         # the reference does not
+    assert sorted(m[0] for m in t.get_molecules()) == sorted(m[0] for m in g["molecules"])
+    assert len(pq.log) == g["n_pops"]
+
+
 @pytest.mark.parametrize("tag", ["t64", "t1024"])
 def test_traverser_reproduces_reference_traversal_tanimoto_scores(tag):
     from rad_amd.priority_queue import InProcessPQ

@@ -548,8 +548,9 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
     if (max_batch > 65536) max_batch = 65536;
     std::lock_guard<std::mutex> lk(idx->mu);
     RH_REQUIRE_FULL_CORPUS(idx);
-    if (idx->has_graph && !idx->h_graph_valid && idx->g_n) {
-        // graph generated on the device (synthetic): mirror levels / upper rows first
+    if (idx->has_graph && idx->g_n && (idx->h_levels.size() != idx->g_n || idx->h_upper_row.size() != idx->g_n)) {
+        // graph generated on the device (synthetic): mirror it once; after that add() keeps levels / upper rows
+        // itself (the adjacency rows are not needed on the host here)
         RH_TRY(rh_ensure_host_graph(idx));
     }
     if (idx->has_vectors && idx->has_graph && idx->n != idx->g_n)
@@ -577,38 +578,63 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
     }
     const uint64_t old_nu = idx->n_upper_rows;
 
-    // ---- grow device arrays (exact size; add() is called with large chunks) ---------
+    // Nothing of the index object changes until the last batch is linked: a failure in between (a HIP error, a
+    // device structure that overflowed) leaves the index as it was and extendable (the arrays may keep their
+    // larger allocations, their contents beyond the old size are never read).
+    bool committed = false;
+    auto rollback = [&]() { hl.resize(first); hu.resize(first); };
+    // ---- grow device arrays: by half at least, so that many small add() calls stay linear ---------
     {
-        uint4 *nfp = nullptr;
-        RH_HIP(hipMalloc((void **)&nfp, total * idx->row_stride));
-        if (idx->d_fp && first) RH_HIP(hipMemcpy(nfp, idx->d_fp, first * idx->row_stride, hipMemcpyDeviceToDevice));
-        if (idx->d_fp) (void)hipFree(idx->d_fp);
-        idx->d_fp = nfp;
-        idx->device_bytes += count * idx->row_stride;
+        const uint64_t need = total, have = idx->d_fp ? idx->fp_cap_rows : 0;
+        if (need > have) {
+            uint64_t ncap = std::max<uint64_t>(need, have + have / 2);
+            uint4 *nfp = nullptr;
+            hipError_t e = hipMalloc((void **)&nfp, ncap * idx->row_stride);
+            if (e != hipSuccess && ncap > need) { ncap = need; e = hipMalloc((void **)&nfp, ncap * idx->row_stride); }   // tight on memory: exact size
+            if (e != hipSuccess) { rollback(); RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP, "hipMalloc for %llu rows failed: %s", (unsigned long long)need, hipGetErrorString(e)); }
+            if (idx->d_fp && first && hipMemcpy(nfp, idx->d_fp, first * idx->row_stride, hipMemcpyDeviceToDevice) != hipSuccess) {
+                (void)hipFree(nfp); rollback(); RH_FAIL(RADHIP_E_HIP, "device copy of the corpus failed");
+            }
+            if (idx->d_fp) { (void)hipFree(idx->d_fp); idx->device_bytes -= std::min<uint64_t>(idx->device_bytes, have * idx->row_stride); }
+            idx->d_fp = nfp;
+            idx->fp_cap_rows = ncap;
+            idx->device_bytes += ncap * idx->row_stride;
+        }
         std::vector<uint8_t> stage((size_t)count * idx->row_stride, 0);
         for (uint64_t i = 0; i < count; ++i)
             memcpy(stage.data() + i * idx->row_stride, rows + i * idx->row_bytes, idx->row_bytes);
-        RH_HIP(hipMemcpy((uint8_t *)idx->d_fp + first * idx->row_stride, stage.data(), stage.size(), hipMemcpyHostToDevice));
-        idx->fp_cap_rows = total;
+        if (hipMemcpy((uint8_t *)idx->d_fp + first * idx->row_stride, stage.data(), stage.size(), hipMemcpyHostToDevice) != hipSuccess) { rollback(); RH_FAIL(RADHIP_E_HIP, "upload of the new rows failed"); }
     }
-    RH_TRY(grow_dev(&idx->d_levels, first, total, idx->stream, &idx->device_bytes));
-    RH_TRY(grow_dev(&idx->d_adj0, first * idx->cap0, total * idx->cap0, idx->stream, &idx->device_bytes));
-    RH_TRY(grow_dev(&idx->d_upper_row, first, total, idx->stream, &idx->device_bytes));
-    RH_TRY(grow_dev(&idx->d_adjU, old_nu * idx->M, nu * idx->M, idx->stream, &idx->device_bytes));
-    RH_HIP(hipMemcpy(idx->d_levels + first, hl.data() + first, count, hipMemcpyHostToDevice));
-    RH_HIP(hipMemcpy(idx->d_upper_row + first, hu.data() + first, count * 4, hipMemcpyHostToDevice));
-    RH_HIP(hipMemset(idx->d_adj0 + first * idx->cap0, 0xFF, count * idx->cap0 * 4));
-    if (nu > old_nu) RH_HIP(hipMemset(idx->d_adjU + old_nu * idx->M, 0xFF, (nu - old_nu) * idx->M * 4));
-    idx->n_upper_rows = nu;
-    idx->n = total;
-    idx->has_vectors = true;
+    {
+        int rc = RADHIP_OK;
+        if (total > idx->cap_nodes || !idx->d_levels) {
+            const uint64_t ncap = std::max<uint64_t>(total, idx->cap_nodes + idx->cap_nodes / 2);
+            rc = grow_dev(&idx->d_levels, first, ncap, idx->stream, &idx->device_bytes);
+            if (rc == RADHIP_OK) rc = grow_dev(&idx->d_adj0, first * idx->cap0, ncap * idx->cap0, idx->stream, &idx->device_bytes);
+            if (rc == RADHIP_OK) rc = grow_dev(&idx->d_upper_row, first, ncap, idx->stream, &idx->device_bytes);
+            if (rc == RADHIP_OK) idx->cap_nodes = ncap;
+        }
+        if (rc == RADHIP_OK && (nu > idx->cap_upper || !idx->d_adjU)) {
+            const uint64_t ncap = std::max<uint64_t>(nu, idx->cap_upper + idx->cap_upper / 2);
+            rc = grow_dev(&idx->d_adjU, old_nu * idx->M, ncap * idx->M, idx->stream, &idx->device_bytes);
+            if (rc == RADHIP_OK) idx->cap_upper = ncap;
+        }
+        if (rc != RADHIP_OK) { rollback(); return rc; }
+    }
+    if (hipMemcpy(idx->d_levels + first, hl.data() + first, count, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(idx->d_upper_row + first, hu.data() + first, count * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(idx->d_adj0 + first * idx->cap0, 0xFF, count * idx->cap0 * 4) != hipSuccess ||
+        (nu > old_nu && hipMemset(idx->d_adjU + old_nu * idx->M, 0xFF, (nu - old_nu) * idx->M * 4) != hipSuccess)) {
+        rollback();
+        RH_FAIL(RADHIP_E_HIP, "initialising the new graph rows failed");
+    }
 
     // ---- per-batch scratch ----------------------------------------------------------
     const uint32_t ef = std::max<uint32_t>(idx->ef_add, 1);
     const uint32_t ef_cap = next_pow2(std::max<uint32_t>(ef, 64));
     const size_t lds = wave_lds_bytes(ef_cap);
-    if (lds > 64 * 1024) RH_FAIL(RADHIP_E_INVALID, "expansion_add %u too large for the LDS top buffer", ef);
-    const uint32_t vlog2 = std::min<uint32_t>(20, std::max<uint32_t>(10, log2u(4u * (ef + 64u) * idx->cap0)));
+    if (lds > 64 * 1024) { rollback(); RH_FAIL(RADHIP_E_INVALID, "expansion_add %u too large for the LDS top buffer", ef); }
+    uint32_t vlog2 = std::min<uint32_t>(20, std::max<uint32_t>(10, log2u(4u * (ef + 64u) * idx->cap0)));
     const uint64_t bmax = std::min<uint64_t>(max_batch, count);
     uint32_t *d_vis = nullptr;
     int32_t *d_status = nullptr;
@@ -625,10 +651,11 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
         for (void *p : ps) if (p) (void)hipFree(p);
         d_req = nullptr; d_goff = nullptr; d_keys_a = d_keys_b = nullptr; d_gstart = nullptr; d_tmp = nullptr; tmp_bytes = 0;
     };
-    auto cleanup = [&]() {
+    auto cleanup = [&]() {   // (failure paths only reach it before the commit at the end: the index rolls back)
         if (d_vis) (void)hipFree(d_vis); if (d_status) (void)hipFree(d_status);
         if (d_req_count) (void)hipFree(d_req_count); if (d_ng) (void)hipFree(d_ng);
         free_req();
+        if (!committed) rollback();
     };
 #define BH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { radhip_set_error("%s failed: %s", #x, hipGetErrorString(e_)); cleanup(); return e_ == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP; } } while (0)
     BH(hipMalloc((void **)&d_vis, (bmax << vlog2) * 4));
@@ -664,28 +691,46 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
                 tmp_bytes = std::max(t1, t2) + 256;
                 BH(hipMalloc(&d_tmp, tmp_bytes));
             }
-            BH(hipMemsetAsync(d_req_count, 0, 8, idx->stream));
-            BuildParams BP;
-            BP.G = make_view(idx);
-            BP.batch_start = (uint32_t)start; BP.batch_n = (uint32_t)bs;
-            BP.snap_entry = entry; BP.snap_max_level = max_level;
-            BP.ef = ef; BP.ef_cap = ef_cap; BP.vis = d_vis; BP.vlog2 = vlog2;
-            BP.req = d_req; BP.req_count = d_req_count; BP.req_cap = (uint32_t)std::min<uint64_t>(req_cap, 0xFFFFFFFFull);
-            BP.status = d_status;
-            switch (lpr) {
-                case 1: hipLaunchKernelGGL(build_insert_kernel<1>, dim3((uint32_t)bs), dim3(64), lds, idx->stream, BP); break;
-                case 2: hipLaunchKernelGGL(build_insert_kernel<2>, dim3((uint32_t)bs), dim3(64), lds, idx->stream, BP); break;
-                case 4: hipLaunchKernelGGL(build_insert_kernel<4>, dim3((uint32_t)bs), dim3(64), lds, idx->stream, BP); break;
-                case 8: hipLaunchKernelGGL(build_insert_kernel<8>, dim3((uint32_t)bs), dim3(64), lds, idx->stream, BP); break;
-                default: hipLaunchKernelGGL(build_insert_kernel<16>, dim3((uint32_t)bs), dim3(64), lds, idx->stream, BP); break;
-            }
-            BH(hipGetLastError());
             unsigned long long nreq = 0;
-            BH(hipMemcpyAsync(&nreq, d_req_count, 8, hipMemcpyDeviceToHost, idx->stream));
-            BH(hipMemcpyAsync(hstatus.data(), d_status, bs * 4, hipMemcpyDeviceToHost, idx->stream));
-            BH(hipStreamSynchronize(idx->stream));
-            for (uint64_t b = 0; b < bs; ++b)
-                if (hstatus[b] != 0) { cleanup(); RH_FAIL(hstatus[b], "insert of node %llu overflowed its visited table", (unsigned long long)(start + b)); }
+            for (;;) {
+                BH(hipMemsetAsync(d_req_count, 0, 8, idx->stream));
+                BuildParams BP;
+                BP.G = make_view(idx);
+                BP.batch_start = (uint32_t)start; BP.batch_n = (uint32_t)bs;
+                BP.snap_entry = entry; BP.snap_max_level = max_level;
+                BP.ef = ef; BP.ef_cap = ef_cap; BP.vis = d_vis; BP.vlog2 = vlog2;
+                BP.req = d_req; BP.req_count = d_req_count; BP.req_cap = (uint32_t)std::min<uint64_t>(req_cap, 0xFFFFFFFFull);
+                BP.status = d_status;
+                switch (lpr) {
+                    case 1: hipLaunchKernelGGL(build_insert_kernel<1>, dim3((uint32_t)bs), dim3(64), lds, idx->stream, BP); break;
+                    case 2: hipLaunchKernelGGL(build_insert_kernel<2>, dim3((uint32_t)bs), dim3(64), lds, idx->stream, BP); break;
+                    case 4: hipLaunchKernelGGL(build_insert_kernel<4>, dim3((uint32_t)bs), dim3(64), lds, idx->stream, BP); break;
+                    case 8: hipLaunchKernelGGL(build_insert_kernel<8>, dim3((uint32_t)bs), dim3(64), lds, idx->stream, BP); break;
+                    default: hipLaunchKernelGGL(build_insert_kernel<16>, dim3((uint32_t)bs), dim3(64), lds, idx->stream, BP); break;
+                }
+                BH(hipGetLastError());
+                BH(hipMemcpyAsync(&nreq, d_req_count, 8, hipMemcpyDeviceToHost, idx->stream));
+                BH(hipMemcpyAsync(hstatus.data(), d_status, bs * 4, hipMemcpyDeviceToHost, idx->stream));
+                BH(hipStreamSynchronize(idx->stream));
+                bool overflow = false;
+                for (uint64_t b = 0; b < bs; ++b)
+                    if (hstatus[b] == RADHIP_E_CAPACITY) overflow = true;
+                    else if (hstatus[b] != 0) { const int st_ = hstatus[b]; cleanup(); RH_FAIL(st_, "insert of node %llu failed on the device (status %d)", (unsigned long long)(start + b), st_); }
+                if (!overflow) break;
+                // A search of this batch filled its visited table (duplicate-heavy corpora expand far more nodes than
+                // expansion_add suggests): the batch has only written rows of its own nodes, which are reset, and runs
+                // again with a table twice the size — the result is the one a large table would have given at once.
+                if (vlog2 >= 26) { cleanup(); RH_FAIL(RADHIP_E_CAPACITY, "a search of batch %llu overflowed a 2^26-entry visited table", (unsigned long long)start); }
+                vlog2++;
+                (void)hipFree(d_vis); d_vis = nullptr;
+                BH(hipMalloc((void **)&d_vis, (bmax << vlog2) * 4));
+                BH(hipMemsetAsync(idx->d_adj0 + start * idx->cap0, 0xFF, bs * idx->cap0 * 4, idx->stream));
+                {
+                    uint64_t u0 = RADHIP_NO_SLOT, u1 = 0;
+                    for (uint64_t i = start; i < end; ++i) if (hl[i] > 0) { if (u0 == RADHIP_NO_SLOT) u0 = hu[i]; u1 = (uint64_t)hu[i] + (uint64_t)hl[i]; }
+                    if (u0 != RADHIP_NO_SLOT) BH(hipMemsetAsync(idx->d_adjU + u0 * idx->M, 0xFF, (u1 - u0) * idx->M * 4, idx->stream));
+                }
+            }
             if (nreq > req_cap) { cleanup(); RH_FAIL(RADHIP_E_CAPACITY, "reverse-edge request buffer overflow"); }
             if (nreq) {
                 const uint32_t sgrid = (uint32_t)std::min<uint64_t>((nreq + 255) / 256, 4096);
@@ -718,8 +763,12 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
             if (hl[i] > max_level) { max_level = hl[i]; entry = (uint32_t)i; }
         start = end;
     }
+    committed = true;
     cleanup();
 #undef BH
+    idx->n_upper_rows = nu;
+    idx->n = total;
+    idx->has_vectors = true;
     idx->g_n = total;
     idx->entry = entry;
     idx->max_level = max_level;

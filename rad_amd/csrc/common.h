@@ -73,6 +73,7 @@ struct radhip_index {
     uint32_t n_top = 0;
     bool d_graph_valid = false;
     uint64_t fp_cap_rows = 0;
+    uint64_t cap_nodes = 0, cap_upper = 0;   // allocated rows of d_levels / d_adj0 / d_upper_row and of d_adjU (add() grows them by half)
     uint64_t device_bytes = 0;
     // bumped by every call that changes the graph or the corpus (load_graph, synth_graph, add,
     // load/synth_vectors): traversal objects remember the generation they were sized for

@@ -128,6 +128,8 @@ static int alloc_graph_dev(radhip_index *idx) {
     RH_TRY(dev_alloc(idx, (void **)&idx->d_adj0, idx->g_n * idx->cap0 * 4));
     RH_TRY(dev_alloc(idx, (void **)&idx->d_upper_row, idx->g_n * 4));
     RH_TRY(dev_alloc(idx, (void **)&idx->d_adjU, idx->n_upper_rows * idx->M * 4));
+    idx->cap_nodes = idx->g_n;
+    idx->cap_upper = idx->n_upper_rows;
     return RADHIP_OK;
 }
 

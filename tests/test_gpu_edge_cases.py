@@ -156,3 +156,27 @@ def test_search_rows_shorter_than_k_are_padded(gpu, oracle):
         assert (m.counts == 20).all()
         assert (m.slots[:, 20:] == NO_SLOT).all() and (m.slots[:, :20] < 20).all()
         assert (m.keys[:, 20:] == 0).all()
+
+
+def test_add_survives_visited_table_overflow_and_stays_extendable(gpu, oracle):
+    """A corpus of near-duplicates makes an insert's layer search visit far more nodes than expansion_add
+    suggests (equal distances admit every smaller slot): the per-insert visited table overflows.  The library
+    re-runs the batch with a larger table instead of failing — the graph is the oracle's, and the index can
+    still be extended afterwards (add() used to be left half-committed)."""
+    from rad_amd.index import Index
+    rng = np.random.default_rng(5)
+    n, ndim, M, ef = 9000, 64, 4, 8
+    base = np.packbits(rng.integers(0, 2, (3, ndim), dtype=np.uint8), axis=1)
+    X = base[rng.integers(0, 3, n)].copy()                    # three distinct fingerprints, 3000 copies each
+    X[::7, 0] ^= rng.integers(0, 4, X[::7, 0].shape, dtype=np.uint8)
+    h = oracle.Hnsw(ndim, M, 2 * M, ef, seed=3)
+    h.add(X[:6000], max_batch=256)
+    h.add(X[6000:], max_batch=256)
+    g = h.graph()
+    idx = Index(ndim=ndim, connectivity=M, expansion_add=ef, seed=3, max_batch=256)
+    idx.add(np.arange(6000), X[:6000])
+    idx.add(np.arange(6000, n), X[6000:])                     # a second call after whatever the first one hit
+    levels, adj0, upper_row, adjU = idx.device_index().read_graph()
+    assert len(idx) == n and np.array_equal(levels, g.levels)
+    assert np.array_equal(adj0, g.adj0) and np.array_equal(adjU, g.adjU)
+    assert idx.get_node_ids_from_keys([0, 8999]).tolist() == [0, 8999]

@@ -106,7 +106,8 @@ struct TravParams {
     uint64_t pq_cap;
     unsigned long long *stg_save;  // [nq * S_CAP]
     unsigned long long *r_save;    // [nq * RK * 64] near keys
-    uint2 *runs;                   // [nq * MAX_RUNS] {pos, end}
+    uint32_t max_runs;             // run-table entries per traversal: 8192, more for n_to_score beyond ~400k
+    uint2 *runs;                   // [nq * max_runs] {pos, end}
     unsigned long long *rhead;     // [nq * MAX_RUNS] head key of every run (INF = exhausted)
     unsigned long long *midpool;   // trav4_kernel: [nq * 256] the sorted mid run of every traversal
     uint32_t *poplog_nodes;
@@ -221,8 +222,8 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
     const uint64_t ut_limit = ((uint64_t)1 << P.ut_log2) - ((uint64_t)1 << P.ut_log2) / 4;
     uint2 *scored = P.scored + (uint64_t)q * P.scored_cap;
     unsigned long long *pq = P.pq + (uint64_t)q * P.pq_cap;
-    uint2 *runs = P.runs + (uint64_t)q * MAX_RUNS;
-    unsigned long long *rhead = P.rhead + (uint64_t)q * MAX_RUNS;
+    uint2 *runs = P.runs + (uint64_t)q * P.max_runs;
+    unsigned long long *rhead = P.rhead + (uint64_t)q * P.max_runs;
     const uint32_t chunk = lane % LPR;
     const uint4 qv = P.queries[(uint64_t)q * LPR + chunk];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
     // ---- far: flush staging into a new sorted run --------------------------------
     auto flush = [&]() {
         if (cnt == 0) return;
-        if (n_runs >= MAX_RUNS || pq_used + cnt > P.pq_cap) { status = RADHIP_E_CAPACITY; return; }
+        if (n_runs >= P.max_runs || pq_used + cnt > P.pq_cap) { status = RADHIP_E_CAPACITY; return; }
         uint32_t Pw = 2;
         while (Pw < cnt) Pw <<= 1;
         for (uint32_t i = cnt + lane; i < Pw; i += 64) L.stg[i] = RH_KEY_INF;
@@ -681,7 +682,7 @@ static uint32_t log2_ceil(uint64_t x) {
 
 static int trav_upload_queries(radhip_traversal *t, const uint8_t *queries) {
     radhip_index *idx = t->idx;
-    if (t->use_gt && queries != t->h_queries.data()) {
+    if (queries != t->h_queries.data()) {   // host copy: the capacity fallbacks of run() re-arm the batch themselves
         try { t->h_queries.assign(queries, queries + (size_t)t->nq * idx->row_bytes); }
         catch (...) { RH_FAIL(RADHIP_E_NOMEM, "out of host memory"); }
     }
@@ -827,8 +828,11 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     t->scored_bytes = (size_t)nq * scored_cap * sizeof(uint2);
     t->pq_bytes = (size_t)nq * pq_cap * 8;
     t->stg_bytes = (size_t)nq * S_CAP * 8;
-    t->runs_bytes = (size_t)nq * MAX_RUNS * sizeof(uint2);
-    t->rhead_bytes = (size_t)nq * MAX_RUNS * 8;
+    // a far run is written by a staging flush (64-256 keys) and stays in the table while it holds a key:
+    // scored_cap / 48 entries cover that with a margin, 8192 at least (exhausted runs are collected on the device)
+    P.max_runs = std::max<uint32_t>(MAX_RUNS, 1u << log2_ceil(scored_cap / 48 + 1));
+    t->runs_bytes = (size_t)nq * P.max_runs * sizeof(uint2);
+    t->rhead_bytes = (size_t)nq * P.max_runs * 8;
     t->rsave_bytes = (size_t)nq * RK * 64 * 8;
     int rc = RADHIP_OK;
 #define RH_A(ptr, bytes)                                                                   \
@@ -949,6 +953,40 @@ static int trav_fall_back_to_hash(radhip_traversal *t) {
     return RADHIP_OK;
 }
 
+// The set of (node, level >= 1) visits and the key pool are sized by an estimate of how much of a traversal
+// happens above level 0 (scored_cap * 8 / connectivity): a traversal that stays on the upper levels (wide
+// upper rows, tiny n_to_score against a tall graph) can exceed it.  The reference has no such limit
+// (rad/visited.py is a Redis set): the batch is re-armed with four times the room and run again.
+static int trav_grow_upper(radhip_traversal *t) {
+    if (t->P.ut_log2 + 2 > 31) RH_FAIL(RADHIP_E_CAPACITY, "the upper-level visited set cannot grow any further");
+    TravParams &P = t->P;
+    (void)hipFree(P.ut); P.ut = nullptr; t->state_bytes -= t->ut_bytes;
+    (void)hipFree(P.pq); P.pq = nullptr; t->state_bytes -= t->pq_bytes;
+    P.ut_log2 += 2;
+    P.pq_cap = P.scored_cap + ((uint64_t)1 << P.ut_log2);
+    if (P.pq_cap >= 0xFFFFFFFFull) RH_FAIL(RADHIP_E_CAPACITY, "the key pool cannot grow any further");
+    t->ut_bytes = ((size_t)t->nq << P.ut_log2) * 8;
+    t->pq_bytes = (size_t)t->nq * P.pq_cap * 8;
+    hipError_t e = hipMalloc((void **)&P.ut, t->ut_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&P.pq, t->pq_bytes);
+    if (e == hipSuccess && P.poplog_nodes) {
+        (void)hipFree(P.poplog_nodes); (void)hipFree(P.poplog_levels);
+        P.poplog_nodes = nullptr; P.poplog_levels = nullptr;
+        P.poplog_cap = P.pq_cap;
+        e = hipMalloc((void **)&P.poplog_nodes, (size_t)t->nq * P.poplog_cap * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&P.poplog_levels, (size_t)t->nq * P.poplog_cap);
+    }
+    if (e != hipSuccess) RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP,
+                                 "growing the traversal state failed: %s", hipGetErrorString(e));
+    t->state_bytes += t->ut_bytes + t->pq_bytes;
+    t->fresh_tables = true;
+    const double ms = t->kernel_ms;
+    const uint64_t launches = t->launches;
+    RH_TRY(trav_upload_queries(t, t->h_queries.data()));
+    t->kernel_ms = ms; t->launches = launches;
+    return RADHIP_OK;
+}
+
 extern "C" int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, uint32_t *out_running) {
     if (!t) RH_FAIL(RADHIP_E_INVALID, "null traversal");
     radhip_index *idx = t->idx;
@@ -970,8 +1008,9 @@ extern "C" int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, ui
             if (hdr[i].status == 0) running++;  // status 3 (intermediate target reached) is parked, not running
             if (hdr[i].status < 0 && !bad) bad = hdr[i].status;
         }
-        if (bad == RADHIP_E_CAPACITY && t->use_gt && first_launch && attempt == 0) {
-            RH_TRY(trav_fall_back_to_hash(t));
+        if (bad == RADHIP_E_CAPACITY && first_launch && attempt < 4) {   // nothing was returned to the caller yet
+            if (t->use_gt) RH_TRY(trav_fall_back_to_hash(t));
+            else RH_TRY(trav_grow_upper(t));
             continue;
         }
         if (out_running) *out_running = running;

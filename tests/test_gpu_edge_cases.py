@@ -180,3 +180,53 @@ def test_add_survives_visited_table_overflow_and_stays_extendable(gpu, oracle):
     assert len(idx) == n and np.array_equal(levels, g.levels)
     assert np.array_equal(adj0, g.adj0) and np.array_equal(adjU, g.adjU)
     assert idx.get_node_ids_from_keys([0, 8999]).tolist() == [0, 8999]
+
+
+def test_long_traversal_1_2m_scored_four_per_wavefront(gpu, oracle, monkeypatch):
+    """n_to_score = 1.2M in trav4_kernel: ~10^4 staging flushes per traversal.  The run table and the key pool
+    are garbage-collected on the device (the 8192-entry run table used to overflow here)."""
+    from rad_amd.device import DeviceIndex, DeviceTraversal
+    monkeypatch.setenv("RADHIP_TRAV", "4")
+    n, nts = 3_000_000, 1_200_000
+    idx = DeviceIndex(1024, 8, 16, 64)
+    idx.synth_vectors(n, seed=5, mode=1)
+    idx.synth_graph(seed=9)
+    X = oracle.synth_rows(0, n, n, 1024, 5, 1)
+    g = oracle.synth_graph(n, 8, 16, 9)
+    Q = X[[7, 1_500_000, 2_999_999]].copy()
+    t = DeviceTraversal(idx, Q, nts)
+    assert t.kernel == "trav4_kernel" and t.run() == 0
+    st = t.stats()
+    assert (st.n_flush > 4000).all()
+    for i in range(3):
+        want = oracle.rad_traverse(g, X, Q[i], nts, log_pops=False)
+        s, a, o = t.results(i)
+        assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt)
+        assert st.n_pops[i] == want.n_pops
+
+
+def test_traversal_that_lives_on_the_upper_levels(gpu, oracle, trav_mode):
+    """Most nodes of this graph sit above level 0 and the upper rows are wide: the (node, level >= 1) visited
+    set outgrows the estimate it was sized by.  The library re-arms the batch with more room
+    instead of failing with RADHIP_E_CAPACITY; results equal the oracle's."""
+    import test_gpu_fuzz as F
+    from rad_amd.device import DeviceIndex, DeviceTraversal
+    rng = np.random.default_rng(12)
+    n, M, cap0, max_level = 60000, 16, 16, 6
+    g = F._random_graph(oracle, rng, n, M, cap0, max_level, 0.0)
+    lv = g.levels.copy()
+    X = F._random_rows(rng, n, 1024, 0.0)
+    idx = DeviceIndex(1024, M, cap0, 32)
+    idx.load_vectors(X)
+    idx.load_graph(g.levels, g.adj0, g.upper_row, g.adjU, g.max_level, g.entry)
+    Q = X[rng.integers(0, n, 5)].copy()
+    nts = 30000
+    t = DeviceTraversal(idx, Q, nts, log_pops=True)
+    assert t.run() == 0
+    for i in range(5):
+        want = oracle.rad_traverse(g, X, Q[i], nts)
+        s, a, o = t.results(i)
+        nodes, levels = t.pop_log(i)
+        assert np.array_equal(nodes, want.pop_nodes) and np.array_equal(levels, want.pop_levels)
+        assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt)
+    assert (lv > 0).mean() > 0.3

@@ -16,11 +16,16 @@ Corpus, graph and state are resident in HBM before the timed region starts.
 N > 1: `python bench.py --gpus N` spawns its own N rank processes (before any HIP call; also runs under
 `python -m torch.distributed.run`, reading RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).  Rendezvous is a
 plain TCP star (rad_amd/rendezvous.py); the exchange of the data path is RCCL inside the library.
-  --mode sharded   (default) BASELINE's partitioning: ONE graph over the whole corpus, rows and
-                   traversals partitioned over the ranks, per frontier step an RCCL all-gather of the
-                   candidate slots and a reduce-scatter of their scores; results bit-identical to one GPU
-  --mode replicas  every GPU holds the whole corpus, the queries are split, no collective
-Both are measured in every N > 1 run; `value` comes from --mode, the other is reported beside it.
+  --mode replicas  (default) the independent units of this path are the traversals: every GPU holds the
+                   whole corpus and graph (20 GB of 288), the query batches are split, no collective
+  --mode sharded   BASELINE's partitioning: ONE graph over the whole corpus, rows and traversals
+                   partitioned over the ranks, per frontier step an RCCL all-gather of the candidate
+                   slots and a reduce-scatter of their scores; results bit-identical to one GPU
+BOTH legs run in every N > 1 bench (the sharded one parity-checked against the single-GPU kernel); `value`
+comes from --mode, the other leg is reported beside it.  Strict best-first over remote rows costs two
+collectives per frontier step and ~10^4 steps per batch: it is the mode for a corpus that does not fit one
+GPU, not the throughput mode ("if RCCL latency dominates: replicas ... state which mode
+each number comes from").
 
 Prints ONE JSON line on rank 0.
 """
@@ -71,7 +76,9 @@ def parse_args():
     ap.add_argument("--no-reference-corpus", action="store_true", help="skip the round-1 corpus leg (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work the cpu_baseline sample should take at least")
-    ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded", help="which N > 1 mode `value` reports")
+    ap.add_argument("--mode", choices=["sharded", "replicas"], default="replicas", help="which N > 1 leg `value` reports (both always run)")
+    ap.add_argument("--sharded-timeout", type=float, default=420.0,
+                    help="seconds the sharded leg may take before the line is printed without it (a hung collective must not cost the run)")
     ap.add_argument("--sharded-nq", type=int, default=2048, help="traversals per rank and step of the sharded leg")
     ap.add_argument("--exchange", choices=["rccl", "host", "gloo"], default="rccl",
                     help="sharded leg: rccl (product: device buffers, one stream) or host (rehearsal of N ranks on one GPU: "
@@ -430,7 +437,30 @@ def main():
             pass
 
     if world > 1:
-        sh = run_sharded_leg(args, idx, grp, rank, world, local_rank, barrier)
+        box = {}
+
+        def _leg():
+            try:
+                box["res"] = run_sharded_leg(args, idx, grp, rank, world, local_rank, barrier)
+            except BaseException as e:   # noqa: BLE001 - reported in the line, never silent
+                box["err"] = f"{type(e).__name__}: {e}"
+        th = threading.Thread(target=_leg, daemon=True)
+        th.start()
+        th.join(args.sharded_timeout)
+        if th.is_alive() or "err" in box:
+            # the replicas leg is measured: print the line with what went wrong in the sharded leg and leave
+            # (no further collective: the other ranks are in the same state or gone)
+            why = box.get("err", f"no result after {args.sharded_timeout:.0f} s (hung collective?)")
+            if rank == 0:
+                if args.mode == "sharded":
+                    print(f"bench.py: the sharded leg failed ({why}) and --mode sharded asked for its value", file=sys.stderr)
+                    os._exit(4)
+                config["parallelism"] = "replicas (--mode replicas): every GPU holds the whole corpus and graph, the query batch is split, no collective"
+                out["sharded"] = {"error": why}
+                out["replicas"] = {"value": value_replicas, "unit": "expansions/s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0 if args.mode == "replicas" else 4)
+        sh = box["res"]
         tot = grp.allreduce([sh["pops"], sh["evals"], sh["parity_ok"], sh["parity_n"]], "sum")
         el = float(grp.allreduce([sh["elapsed"]], "max")[0])
         sharded = {

@@ -53,7 +53,7 @@ def test_bench_json_contract(gpu):
 def test_bench_two_ranks_from_a_bare_invocation(gpu):
     """no launcher: bench.py spawns its ranks itself; two ranks share GPU 0, so the exchange is host-staged"""
     j = _run("--gpus", "2", "--steps", "1", "--warmup", "1", "--rows", "200000", "--nq", "512", "--n-to-score", "1500",
-             "--sharded-nq", "64", "--exchange", "host", "--single-device")
+             "--sharded-nq", "64", "--exchange", "host", "--single-device", "--mode", "sharded")
     _contract(j, 2, 1)
     sh, rp = j["sharded"], j["replicas"]
     assert j["value"] == sh["value"] > 0 and rp["value"] > 0
@@ -62,5 +62,6 @@ def test_bench_two_ranks_from_a_bare_invocation(gpu):
     assert sh["frontier_steps_per_step"] > 10 and sh["exchanged_bytes_per_rank_per_step"] > 0
     assert "row-sharded" in j["config"]["parallelism"] and "host-staged" in sh["exchange"]
     j2 = _run("--gpus", "2", "--steps", "1", "--warmup", "1", "--rows", "200000", "--nq", "512", "--n-to-score", "1500",
-              "--sharded-nq", "64", "--exchange", "host", "--single-device", "--mode", "replicas")
+              "--sharded-nq", "64", "--exchange", "host", "--single-device")            # default: value from the replicas leg
     assert j2["value"] == j2["replicas"]["value"] and "replicas" in j2["config"]["parallelism"]
+    assert j2["sharded"]["parity_vs_single_gpu"] == "128/128"                             # the sharded leg still ran

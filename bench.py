@@ -79,7 +79,7 @@ def parse_args():
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="replicas", help="which N > 1 leg `value` reports (both always run)")
     ap.add_argument("--sharded-timeout", type=float, default=420.0,
                     help="seconds the sharded leg may take before the line is printed without it (a hung collective must not cost the run)")
-    ap.add_argument("--sharded-nq", type=int, default=2048, help="traversals per rank and step of the sharded leg")
+    ap.add_argument("--sharded-nq", type=int, default=8192, help="traversals per rank and step of the sharded leg")
     ap.add_argument("--exchange", choices=["rccl", "host", "gloo"], default="rccl",
                     help="sharded leg: rccl (product: device buffers, one stream) or host (rehearsal of N ranks on one GPU: "
                          "host-staged buffers over the TCP group; `gloo` is an alias)")
@@ -324,9 +324,11 @@ def run_sharded_leg(args, idx, grp, rank, world, local_rank, barrier):
     res = {"steps": 0, "bytes": 0, "pops": 0, "evals": 0}
     last = None
 
+    sh = DeviceShard(idx, rank, world, first, count, Qall[0], args.n_to_score)
+
     def one(b):
         nonlocal last
-        sh = DeviceShard(idx, rank, world, first, count, Qall[b], args.n_to_score)
+        sh.reset(Qall[b])
         if use_host:
             drv = RowShardedTraversal(sh, grp.allgather_u32, grp.reduce_scatter_sum_u32, rank, world)
             steps, xb = drv.run(), 0
@@ -335,7 +337,6 @@ def run_sharded_leg(args, idx, grp, rank, world, local_rank, barrier):
             steps = sh.run(comm)
             xb = sh.timing()[3]
         st = sh.stats()
-        sh.close()
         last = st
         return steps, xb, int(st.n_pops.sum()), int(st.n_scored.sum())
 
@@ -350,6 +351,7 @@ def run_sharded_leg(args, idx, grp, rank, world, local_rank, barrier):
     res["elapsed"] = time.perf_counter() - t0
     good = int(((last.n_scored == want.n_scored) & (last.n_pops == want.n_pops) & (last.n_nbr == want.n_nbr)).sum())
     res["parity_ok"], res["parity_n"] = good, nq
+    sh.close()
     res["exchange"] = ("host-staged buffers over the TCP group" if use_host else "RCCL ncclAllGather + ncclReduceScatter on device buffers") + note
     if comm is not None:
         comm.close()

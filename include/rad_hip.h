@@ -295,6 +295,8 @@ int radhip_shard_create(radhip_index_t *idx, int rank, int world, uint64_t row_f
                         const uint8_t *queries_all, uint32_t nq, uint64_t n_to_score, uint32_t flags,
                         radhip_shard_t **out);
 int radhip_shard_destroy(radhip_shard_t *s);
+/* re-arm the same state for a new batch of world * nq queries */
+int radhip_shard_reset(radhip_shard_t *s, const uint8_t *queries_all);
 /* the product loop: step kernel, ncclAllGather of the candidates, evaluation kernel, ncclReduceScatter of
  * the scores — device buffers end to end, one stream — until no rank has a live traversal (the live counts
  * travel behind the candidates, so all ranks stop at the same step) or max_steps (0 = none) */

@@ -99,6 +99,7 @@ SIGNATURES = {
     "radhip_index_keep_rows": (C.c_int, [_P, _U64, _U64]),
     "radhip_shard_create": (C.c_int, [_P, C.c_int, C.c_int, _U64, _U64, _P, _U32, _U64, _U32, C.POINTER(_P)]),
     "radhip_shard_destroy": (C.c_int, [_P]),
+    "radhip_shard_reset": (C.c_int, [_P, _P]),
     "radhip_shard_run": (C.c_int, [_P, _P, _U64, C.POINTER(_U64)]),
     "radhip_shard_width": (_U32, [_P]),
     "radhip_shard_step": (C.c_int, [_P, C.POINTER(_U32)]),

@@ -298,8 +298,10 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     const uint64_t n_top = idx->n_top;
     const uint64_t scored_cap = s->n_to_score + W + n_top;
     const uint64_t up_pairs = idx->n_upper_rows + n_top * (uint64_t)(idx->max_level + 1);
-    const uint64_t heap_cap = scored_cap + std::min<uint64_t>(up_pairs, scored_cap * (uint64_t)(idx->max_level + 1)) + 64;
-    const uint32_t vlog2 = std::max<uint32_t>(8, sh_log2_ceil(2 * heap_cap));
+    // queue entries = scored nodes (one level-0 entry each) + visits above level 0: the traversal kernels' estimate
+    // (scored_cap * 8 / connectivity) with a factor of two on top, never more than the graph has
+    const uint64_t heap_cap = scored_cap + std::min<uint64_t>(up_pairs, scored_cap * 16 / idx->M + 4096) + 64;
+    const uint32_t vlog2 = std::max<uint32_t>(8, sh_log2_ceil(heap_cap + heap_cap / 2));
     const uint32_t slog2 = std::max<uint32_t>(8, sh_log2_ceil(2 * scored_cap));
     ShardParams &P = s->P;
     P.adj0 = idx->d_adj0; P.upper_row = idx->d_upper_row; P.adjU = idx->d_adjU; P.top = idx->d_top;
@@ -361,6 +363,37 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     E.first = row_first; E.count = row_count; E.queries = s->d_queries; E.qpop = s->d_qpop;
     E.req_all = s->d_req_all; E.out = s->d_out; E.world = (uint32_t)world; E.nq = nq; E.W = W;
     *out = s;
+    return RADHIP_OK;
+}
+
+// re-arm the same state for a new batch of world * nq queries (bench steps): headers and sets are cleared
+// on the device, nothing is reallocated
+extern "C" int radhip_shard_reset(radhip_shard_t *s, const uint8_t *queries_all) {
+    if (!s || !queries_all) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    radhip_index *idx = s->idx;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (s->graph_gen != idx->graph_gen)
+        RH_FAIL(RADHIP_E_STATE, "the index changed since this sharded traversal was created: create a new one");
+    RH_HIP(hipSetDevice(idx->device));
+    const size_t tq = (size_t)s->world * s->nq, per_rank = (size_t)s->nq * s->W;
+    std::vector<uint8_t> padded(tq * idx->row_stride, 0);
+    std::vector<uint32_t> pop(tq, 0);
+    for (size_t i = 0; i < tq; ++i) {
+        memcpy(padded.data() + i * idx->row_stride, queries_all + i * idx->row_bytes, idx->row_bytes);
+        uint32_t p = 0;
+        for (uint32_t b = 0; b < idx->row_bytes; ++b) p += (uint32_t)__builtin_popcount(queries_all[i * idx->row_bytes + b]);
+        pop[i] = p;
+    }
+    hipStream_t st = idx->stream;
+    RH_HIP(hipMemcpyAsync(s->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, st));
+    RH_HIP(hipMemcpyAsync(s->d_qpop, pop.data(), tq * 4, hipMemcpyHostToDevice, st));
+    RH_HIP(hipMemsetAsync(s->P.hdr, 0, (size_t)s->nq * sizeof(ShardHeader), st));
+    RH_HIP(hipMemsetAsync(s->P.vis, 0, ((size_t)s->nq << s->P.vlog2) * 8, st));
+    RH_HIP(hipMemsetAsync(s->P.sc, 0, ((size_t)s->nq << s->P.slog2) * 8, st));
+    RH_HIP(hipMemsetAsync(s->d_req, 0, (per_rank + 16) * 4, st));
+    RH_HIP(hipMemsetAsync(s->d_in, 0, per_rank * 4, st));
+    RH_HIP(hipStreamSynchronize(st));
+    s->step_ms = 0.0; s->eval_ms = 0.0; s->steps = 0; s->exchanged_bytes = 0;
     return RADHIP_OK;
 }
 

@@ -326,6 +326,12 @@ class DeviceShard:
         except Exception:
             pass
 
+    def reset(self, queries_all: np.ndarray) -> None:
+        q = _lib.as_rows(queries_all, self.index.row_bytes, "queries_all")
+        if q.shape[0] != self.world * self.nq:
+            raise ValueError(f"reset needs exactly {self.world * self.nq} queries")
+        check(self._L.radhip_shard_reset(self._h, ptr(q)))
+
     # -- the product loop (RCCL on device buffers)
     def run(self, comm: "RcclComm", max_steps: int = 0) -> int:
         steps = C.c_uint64(0)

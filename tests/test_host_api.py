@@ -359,3 +359,50 @@ def test_product_never_touches_the_oracle():
     nxt = bench.find("\ndef ", start + 1)
     end = nxt if nxt >= 0 else bench.index("\nif __name__", start)
     assert all(start <= u < end for u in uses), "oracle referenced outside cpu_baseline()"
+
+
+def test_key_map_lives_in_the_library():
+    """key <-> slot map behind the C ABI (host memory, no device): unsorted keys, duplicates (lowest slot wins),
+    unknown keys, partial set_keys (identity keys elsewhere), a million keys without a Python dict."""
+    import ctypes as C
+    from rad_amd import _lib
+    from rad_amd._lib import check, ptr
+    from rad_amd.index import Index
+    L = _lib.lib()
+    z = load_graph_npz("g1t64_graph.npz")
+    n = z["levels"].shape[0]
+    rng = np.random.default_rng(0)
+    keys = rng.permutation(np.arange(n, dtype=np.uint64) * 3 + 50)
+    keys[7] = keys[3]                                        # a duplicate: slot 3 wins
+    idx = Index(ndim=64, connectivity=4, expansion_add=20)
+    idx.load_graph(keys, None, z["levels"], z["adj0"], z["upper_row"], z["adjU"], int(z["max_level"]), int(z["entry"]))
+    assert np.array_equal(idx.keys, keys) and np.array_equal(idx.keys_of([0, 7, n - 1]), keys[[0, 7, n - 1]])
+    probe = np.array([keys[10], keys[3], keys[n - 1]], np.uint64)
+    assert idx.get_node_ids_from_keys(probe).tolist() == [10, 3, n - 1]
+    with pytest.raises(KeyError):
+        idx.get_node_ids_from_keys([np.uint64(1)])          # not a key of this index
+    out = np.empty(2, np.uint32)
+    missing = C.c_uint64(0)
+    q = np.array([keys[5], 2], np.uint64)
+    check(L.radhip_slots_from_keys(idx._dev._h, ptr(q), 2, ptr(out), C.byref(missing)))
+    assert out.tolist() == [5, NO_SLOT] and missing.value == 1
+    with pytest.raises(_lib.RadHipError):
+        idx.keys_of([n])                                     # slot out of range
+    # keys given for a part of the slots only: the rest keep the identity key
+    part = Index(ndim=64, connectivity=4, expansion_add=20)
+    part.load_graph(None, None, z["levels"], z["adj0"], z["upper_row"], z["adjU"], int(z["max_level"]), int(z["entry"]))
+    part._set_keys(100, np.array([9000, 9001], np.uint64))
+    assert part.keys_of([99, 100, 101, 102]).tolist() == [99, 9000, 9001, 102]
+    assert part.get_node_ids_from_keys([9001, 5]).tolist() == [101, 5]
+    # size: a million-node graph, lookups through the sorted array
+    big_n = 1_000_000
+    levels = np.zeros(big_n, np.int8); levels[0] = 1
+    adj0 = np.full((big_n, 8), NO_SLOT, np.uint32); adj0[:, 0] = (np.arange(big_n) + 1) % big_n
+    adjU = np.full((1, 4), NO_SLOT, np.uint32)
+    upper_row = np.full(big_n, NO_SLOT, np.uint32); upper_row[0] = 0
+    bk = (np.arange(big_n, dtype=np.uint64)[::-1] * 11).copy()
+    big = Index(ndim=64, connectivity=4, expansion_add=20)
+    big.load_graph(bk, None, levels, adj0, upper_row, adjU, 1, 0)
+    want = rng.integers(0, big_n, 1000)
+    assert np.array_equal(big.get_node_ids_from_keys(bk[want]), want.astype(np.uint64))
+    assert [int(x) for x in big.get_neighbors(5, 0)] == [6, int(bk[6])]

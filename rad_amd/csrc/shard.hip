@@ -84,10 +84,13 @@ __device__ __forceinline__ void sh_sc_insert(unsigned long long *sc, uint32_t sl
     while (sc[i] != SH_EMPTY64) i = (i + 1) & mask;
     sc[i] = (unsigned long long)(slot + 1u) | ((unsigned long long)val << 32);
 }
+// 8-ary min-heap of u64 keys: a level is one 64-B line, so a pop costs ~log8(n) dependent line reads instead
+// of 2 log2(n) (the step kernel is one thread per traversal: dependent reads are what a step costs)
+#define SH_D 8ull
 __device__ __forceinline__ void sh_heap_push(unsigned long long *h, uint64_t &n, unsigned long long key) {
     uint64_t i = n++;
     while (i > 0) {
-        const uint64_t p = (i - 1) >> 1;
+        const uint64_t p = (i - 1) / SH_D;
         const unsigned long long pk = h[p];
         if (pk <= key) break;
         h[i] = pk;
@@ -100,11 +103,16 @@ __device__ __forceinline__ unsigned long long sh_heap_pop(unsigned long long *h,
     const unsigned long long last = h[--n];
     uint64_t i = 0;
     for (;;) {
-        const uint64_t l = 2 * i + 1, r = l + 1;
-        if (l >= n) break;
-        uint64_t m = l;
-        unsigned long long mk = h[l];
-        if (r < n) { const unsigned long long rk = h[r]; if (rk < mk) { m = r; mk = rk; } }
+        const uint64_t c0 = SH_D * i + 1;
+        if (c0 >= n) break;
+        const uint64_t c1 = c0 + SH_D < n ? c0 + SH_D : n;
+        unsigned long long ck[SH_D];
+#pragma unroll
+        for (uint64_t j = 0; j < SH_D; ++j) ck[j] = c0 + j < c1 ? h[c0 + j] : RH_KEY_INF;   // independent loads of one line
+        uint64_t m = c0;
+        unsigned long long mk = ck[0];
+#pragma unroll
+        for (uint64_t j = 1; j < SH_D; ++j) if (ck[j] < mk) { mk = ck[j]; m = c0 + j; }
         if (mk >= last) break;
         h[i] = mk;
         i = m;
@@ -161,16 +169,69 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
             const uint32_t cap = level == 0 ? P.cap0 : P.capU;
             const uint32_t *row = level == 0 ? P.adj0 + (uint64_t)slot * P.cap0
                                              : P.adjU + ((uint64_t)P.upper_row[slot] + (level - 1u)) * P.capU;
-            for (uint32_t j = 0; j < cap; ++j) {
-                const uint32_t nb = row[j];
-                if (nb == RADHIP_NO_SLOT) break;
-                H.n_nbr++;
-                if (sh_vis_tas(vis, P.vlog2, nb, level)) continue;
-                uint32_t v;
-                if (sh_sc_find(sc, P.slog2, nb, &v)) {
-                    if (H.heap_n >= P.heap_cap) { H.status = RADHIP_E_CAPACITY; break; }
-                    sh_heap_push(heap, H.heap_n, rh_make_key_dev(rh_q24_dev(v & 0xFFFFu, v >> 16), nb, level));
-                } else req[k++] = nb;
+            // 16 neighbours at a time: their first visited-set and scored-set buckets are loaded together (independent
+            // loads, one round trip) before the entries are resolved in row order — a thread's dependent reads are
+            // what a step costs.  A preloaded EMPTY visited bucket is only trusted if no earlier neighbour of this row
+            // was inserted there; the scored set does not change inside this loop.
+            const uint64_t vmask = (1ull << P.vlog2) - 1ull, smask = (1ull << P.slog2) - 1ull;
+            bool row_end = false;
+            for (uint32_t base = 0; base < cap && !row_end && H.status == 0; base += 16) {
+                uint32_t nbv[16];
+                unsigned long long ev[16], es[16];
+                uint64_t hv[16], hs[16], ins[16];
+                uint32_t cnt16 = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 16; ++j) {
+                    nbv[j] = (base + j < cap && !row_end) ? row[base + j] : RADHIP_NO_SLOT;
+                    if (nbv[j] == RADHIP_NO_SLOT) row_end = true; else cnt16 = j + 1;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 16; ++j) {
+                    ev[j] = 0ull; es[j] = 0ull; hv[j] = 0; hs[j] = 0; ins[j] = ~0ull;
+                    if (j < cnt16) {
+                        hv[j] = sh_h64((((unsigned long long)nbv[j] << 4) | level) + 1ull) & vmask;
+                        hs[j] = sh_h64((uint64_t)nbv[j] + 1ull) & smask;
+                        ev[j] = vis[hv[j]];
+                        es[j] = sc[hs[j]];
+                    }
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 16; ++j) {
+                    if (j >= cnt16 || H.status != 0) continue;
+                    const uint32_t nb = nbv[j];
+                    H.n_nbr++;
+                    const unsigned long long k1 = (((unsigned long long)nb << 4) | level) + 1ull;
+                    uint64_t i = hv[j];
+                    unsigned long long e = ev[j];
+                    if (e == SH_EMPTY64) {
+                        bool taken = false;
+#pragma unroll
+                        for (uint32_t t = 0; t < 16; ++t) taken = taken || (t < j && ins[t] == i);
+                        if (taken) e = vis[i];
+                    }
+                    bool seen = false;
+                    for (;;) {
+                        if (e == SH_EMPTY64) { vis[i] = k1; ins[j] = i; break; }
+                        if (e == k1) { seen = true; break; }
+                        i = (i + 1) & vmask;
+                        e = vis[i];
+                    }
+                    if (seen) continue;
+                    uint64_t si = hs[j];
+                    unsigned long long se = es[j];
+                    bool found = false;
+                    uint32_t v = 0;
+                    for (;;) {
+                        if (se == SH_EMPTY64) break;
+                        if ((uint32_t)se == nb + 1u) { found = true; v = (uint32_t)(se >> 32); break; }
+                        si = (si + 1) & smask;
+                        se = sc[si];
+                    }
+                    if (found) {
+                        if (H.heap_n >= P.heap_cap) { H.status = RADHIP_E_CAPACITY; continue; }
+                        sh_heap_push(heap, H.heap_n, rh_make_key_dev(rh_q24_dev(v & 0xFFFFu, v >> 16), nb, level));
+                    } else req[k++] = nb;
+                }
             }
             H.pend_level = level;
             if (H.status == 0 && level > 0) {
@@ -501,16 +562,27 @@ extern "C" int radhip_shard_run(radhip_shard_t *s, radhip_comm_t *comm, uint64_t
     const size_t per_rank = (size_t)s->nq * s->W;
     std::vector<uint32_t> live(s->world);
     uint64_t steps = 0;
+    // RADHIP_SHARD_TIMING=1: per-phase device time of the loop (diagnostic; adds five event records per step)
+    const bool phases = getenv("RADHIP_SHARD_TIMING") != nullptr;
+    hipEvent_t pe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double pms[4] = {0, 0, 0, 0};
+    if (phases) for (auto &e : pe) (void)hipEventCreate(&e);
     RH_HIP(hipEventRecord(s->ev0, st));
     for (;;) {
+        if (phases) (void)hipEventRecord(pe[0], st);
         RH_TRY(shard_enqueue_step(s));
+        if (phases) (void)hipEventRecord(pe[1], st);
         RH_TRY(rh_comm_allgather_dev(comm, s->d_req, s->d_req_all, per_rank + 16, st));
+        if (phases) (void)hipEventRecord(pe[2], st);
         RH_TRY(shard_enqueue_eval(s));
+        if (phases) (void)hipEventRecord(pe[3], st);
         RH_TRY(rh_comm_reduce_scatter_u32_dev(comm, s->d_out, s->d_in, per_rank, st));
+        if (phases) (void)hipEventRecord(pe[4], st);
         // the live counts of all ranks travel behind the candidates: every rank stops at the same step
         for (int r = 0; r < s->world; ++r)
             RH_HIP(hipMemcpyAsync(&live[r], s->d_req_all + (size_t)r * (per_rank + 16) + per_rank, 4, hipMemcpyDeviceToHost, st));
         RH_HIP(hipStreamSynchronize(st));
+        if (phases) for (int i = 0; i < 4; ++i) { float m = 0.f; if (hipEventElapsedTime(&m, pe[i], pe[i + 1]) == hipSuccess) pms[i] += m; }
         steps++;
         s->exchanged_bytes += (uint64_t)s->world * (per_rank + 16) * 4 + (uint64_t)s->world * per_rank * 4;
         uint64_t tot = 0;
@@ -521,6 +593,11 @@ extern "C" int radhip_shard_run(radhip_shard_t *s, radhip_comm_t *comm, uint64_t
     RH_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->step_ms += ms;
+    if (phases) {
+        fprintf(stderr, "[shard] %llu steps, device ms per step: step kernel %.4f, all-gather %.4f, evaluation %.4f, reduce-scatter %.4f; whole loop %.4f\n",
+                (unsigned long long)steps, pms[0] / steps, pms[1] / steps, pms[2] / steps, pms[3] / steps, ms / steps);
+        for (auto &e : pe) if (e) (void)hipEventDestroy(e);
+    }
     s->steps += steps;
     if (out_steps) *out_steps = steps;
     // a device-side failure of any local traversal is an error of the call

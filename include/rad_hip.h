@@ -299,13 +299,19 @@ int radhip_shard_destroy(radhip_shard_t *s);
 int radhip_shard_reset(radhip_shard_t *s, const uint8_t *queries_all);
 /* the product loop: step kernel, ncclAllGather of the candidates, evaluation kernel, ncclReduceScatter of
  * the scores — device buffers end to end, one stream — until no rank has a live traversal (the live counts
- * travel behind the candidates, so all ranks stop at the same step) or max_steps (0 = none) */
+ * travel behind the candidates, so all ranks stop at the same step; the host looks at them every fourth
+ * step, so up to three empty steps may follow the last useful one) or max_steps (0 = none) */
 int radhip_shard_run(radhip_shard_t *s, radhip_comm_t *comm, uint64_t max_steps, uint64_t *out_steps);
 /* the same step in host-staged pieces, for an exchange the host program owns (tests; rehearsing N ranks
  * on one GPU): step -> get_requests | exchange | set_requests_all -> evaluate -> get_scores_out |
  * exchange (sum over ranks of block `rank`) | set_scores_in -> step ...   W = radhip_shard_width() slots
  * per traversal and step (RADHIP_NO_SLOT padded); scores are and | or << 16. */
 uint32_t radhip_shard_width(const radhip_shard_t *s);
+/* which step kernel drives the local traversals: 0 = "thread" (one thread per traversal, heap + sets in HBM; the
+ * default), 1 = "wave" (the single-GPU traversal kernel cut at the fingerprint read, four traversals per
+ * wavefront; RADHIP_SHARD_ENGINE=wave, adjacency rows of <= 16 slots; slower per step, kept as a cross-check).
+ * Same results. */
+int radhip_shard_engine(const radhip_shard_t *s);
 int radhip_shard_step(radhip_shard_t *s, uint32_t *out_live);
 int radhip_shard_get_requests(radhip_shard_t *s, uint32_t *host /* [nq * W] */);
 int radhip_shard_set_requests_all(radhip_shard_t *s, const uint32_t *host_all /* [world * nq * W] */);

@@ -17,11 +17,24 @@
 // engine, tests/test_gpu_sharded.py through these kernels).  What is exchanged per step and rank:
 // nq x W candidate slots (4 B each) out, nq x W packed (and | or << 16) scores back.
 //
-// The step kernel is deliberately simple — one thread per traversal, binary heap and open-addressed sets
-// in HBM, the oracle's stepper restated (oracle/rad_oracle.c orc_stepper_step): a sharded step is bound by
-// the two collectives between its kernels, not by them.
+// Two step engines, same results.  "thread" (the default): shard_step_kernel below, one thread per traversal, an
+// 8-ary heap and open-addressed sets in HBM — the oracle's stepper restated (oracle/rad_oracle.c
+// orc_stepper_step).  "wave" (RADHIP_SHARD_ENGINE=wave; adjacency rows of at most 16 slots): trav4_kernel's
+// sharded form (traverse4.inc, SH = true) — the single-GPU kernel with its three-level queue and tables, four
+// traversals per wavefront, cut at the fingerprint read and resumed by the next launch.  A step is a launch
+// that ends when its slowest traversal has its candidates out, so what counts is the worst-case latency of ONE
+// pop, not throughput: the heap's O(log n) dependent reads are evenly short, the wave kernel's register/LDS
+// queue pays a state restore + save per launch and now and then a 256-key sort or a pass over its far runs.
+// Measured on one MI355X (profiles/r02/README.md §5): thread 66 / 97 us per step at 8192 / 30720 traversals,
+// wave 91 / 171 us — the wave engine stays as the second implementation the tests cross-check.
 #include "common.h"
 #include "comm.h"
+
+struct radhip_traversal;
+int rh_trav_create_sharded(radhip_index *idx, const uint8_t *queries, uint32_t nq, uint64_t n_to_score, uint32_t flags,
+                           radhip_traversal **out);                                                       // traverse.hip
+void rh_trav_bind_shard(radhip_traversal *t, uint32_t *d_req, const uint32_t *d_in, uint32_t W, uint32_t max_inner);
+int rh_trav_enqueue_shard_step(radhip_traversal *t);
 
 #include <algorithm>
 #include <new>
@@ -86,7 +99,9 @@ __device__ __forceinline__ void sh_sc_insert(unsigned long long *sc, uint32_t sl
 }
 // 8-ary min-heap of u64 keys: a level is one 64-B line, so a pop costs ~log8(n) dependent line reads instead
 // of 2 log2(n) (the step kernel is one thread per traversal: dependent reads are what a step costs)
+#ifndef SH_D
 #define SH_D 8ull
+#endif
 __device__ __forceinline__ void sh_heap_push(unsigned long long *h, uint64_t &n, unsigned long long key) {
     uint64_t i = n++;
     while (i > 0) {
@@ -258,6 +273,7 @@ struct EvalParams {
     const uint32_t *qpop;        // [world * nq]
     const uint32_t *req_all;     // [world][nq * W + 16]
     uint32_t *out;               // [world][nq * W]
+    uint32_t *live;              // this rank's live count (behind its own candidates): zeroed here for the next step
     uint32_t world, nq, W;
 };
 
@@ -268,6 +284,7 @@ __global__ __launch_bounds__(256) void shard_eval_kernel(EvalParams P) {
     const uint64_t per_rank = (uint64_t)P.nq * P.W, total = per_rank * P.world;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.live = 0u;   // (the all-gather before this kernel has taken it)
     for (uint64_t base = wave * (GPW * U); base < total; base += n_waves * (GPW * U)) {
         uint32_t sl[U];
         uint64_t at[U];
@@ -314,6 +331,7 @@ struct radhip_shard {
     uint32_t *d_qpop = nullptr, *d_req = nullptr, *d_req_all = nullptr, *d_out = nullptr, *d_in = nullptr;
     uint64_t graph_gen = 0;
     size_t state_bytes = 0;
+    radhip_traversal *wave = nullptr;   // the wave engine's state (null: thread engine)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double step_ms = 0.0, eval_ms = 0.0;
     uint64_t steps = 0, exchanged_bytes = 0;
@@ -323,6 +341,7 @@ static uint32_t sh_log2_ceil(uint64_t x) { uint32_t l = 0; while (((uint64_t)1 <
 
 extern "C" int radhip_shard_destroy(radhip_shard_t *s) {
     if (!s) return RADHIP_OK;
+    if (s->wave) (void)radhip_traversal_destroy(s->wave);
     if (s->idx && s->idx->dev_ready) (void)hipSetDevice(s->idx->device);
     void *ps[] = {s->d_queries, s->d_qpop, s->d_req, s->d_req_all, s->d_out, s->d_in, s->P.hdr, s->P.heap, s->P.vis, s->P.sc,
                   s->P.scored, s->P.poplog_nodes, s->P.poplog_levels};
@@ -343,15 +362,28 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     if (row_first + row_count > idx->g_n) RH_FAIL(RADHIP_E_RANGE, "rows [%llu, %llu) exceed the graph's %llu nodes",
                                                   (unsigned long long)row_first, (unsigned long long)(row_first + row_count),
                                                   (unsigned long long)idx->g_n);
-    std::lock_guard<std::mutex> lk(idx->mu);
-    RH_TRY(rh_ensure_device(idx));
     // the rows this rank evaluates must be resident: either the whole corpus or exactly this shard
     if (!(idx->shard_first <= row_first && row_first + row_count <= idx->shard_first + idx->n))
         RH_FAIL(RADHIP_E_STATE, "rows [%llu, %llu) are not resident in this index (it holds [%llu, %llu))",
                 (unsigned long long)row_first, (unsigned long long)(row_first + row_count),
                 (unsigned long long)idx->shard_first, (unsigned long long)(idx->shard_first + idx->n));
+    radhip_traversal *wave = nullptr;
+    {
+        const char *e = getenv("RADHIP_SHARD_ENGINE");
+        const bool want_wave = e && e[0] == 'w';
+        if (want_wave && std::max<uint32_t>(idx->cap0, idx->M) > 16)
+            RH_FAIL(RADHIP_E_INVALID, "RADHIP_SHARD_ENGINE=wave needs adjacency rows of at most 16 slots");
+        if (want_wave)   // (takes the index lock itself)
+            RH_TRY(rh_trav_create_sharded(idx, queries_all + (size_t)rank * nq * idx->row_bytes, nq, n_to_score, flags, &wave));
+    }
+    std::unique_lock<std::mutex> lk(idx->mu);
+    {
+        const int rc0 = rh_ensure_device(idx);
+        if (rc0 != RADHIP_OK) { lk.unlock(); if (wave) (void)radhip_traversal_destroy(wave); return rc0; }
+    }
     radhip_shard *s = new (std::nothrow) radhip_shard();
-    if (!s) RH_FAIL(RADHIP_E_NOMEM, "out of host memory");
+    if (!s) { lk.unlock(); if (wave) (void)radhip_traversal_destroy(wave); RH_FAIL(RADHIP_E_NOMEM, "out of host memory"); }
+    s->wave = wave;
     s->idx = idx; s->rank = rank; s->world = world; s->nq = nq; s->n_to_score = std::min<uint64_t>(n_to_score, idx->g_n);
     s->first = row_first; s->count = row_count; s->graph_gen = idx->graph_gen;
     const uint32_t W = std::max<uint32_t>(idx->cap0, idx->M);
@@ -369,7 +401,10 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     P.n_top = idx->n_top; P.cap0 = idx->cap0; P.capU = idx->M; P.nq = nq; P.W = W;
     P.start_level = idx->max_level > 0 ? idx->max_level - 1 : 0;
     P.n_to_score = s->n_to_score; P.heap_cap = heap_cap; P.vlog2 = vlog2; P.slog2 = slog2; P.scored_cap = scored_cap;
-    P.max_inner = 8;
+    // pops per step while nothing needs a score: the step ends with its slowest traversal, so a long inner loop
+    // makes every step as slow as the unluckiest of thousands of traversals (measured: 2 beats 1, 4 and 8)
+    P.max_inner = 2;
+    if (const char *e = getenv("RADHIP_SHARD_INNER")) { const int v = atoi(e); if (v >= 1 && v <= 64) P.max_inner = (uint32_t)v; }
     int rc = RADHIP_OK;
     const size_t per_rank = (size_t)nq * W;
     auto al = [&](void **p, size_t bytes, bool zero) {
@@ -383,18 +418,20 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
         s->state_bytes += bytes;
         if (zero && hipMemsetAsync(*p, 0, bytes ? bytes : 16, idx->stream) != hipSuccess) rc = RADHIP_E_HIP;
     };
-    al((void **)&P.hdr, (size_t)nq * sizeof(ShardHeader), true);
-    al((void **)&P.heap, (size_t)nq * heap_cap * 8, false);
-    al((void **)&P.vis, ((size_t)nq << vlog2) * 8, true);
-    al((void **)&P.sc, ((size_t)nq << slog2) * 8, true);
-    al((void **)&P.scored, (size_t)nq * scored_cap * sizeof(uint2), false);
+    if (!wave) {
+        al((void **)&P.hdr, (size_t)nq * sizeof(ShardHeader), true);
+        al((void **)&P.heap, (size_t)nq * heap_cap * 8, false);
+        al((void **)&P.vis, ((size_t)nq << vlog2) * 8, true);
+        al((void **)&P.sc, ((size_t)nq << slog2) * 8, true);
+        al((void **)&P.scored, (size_t)nq * scored_cap * sizeof(uint2), false);
+    } else s->state_bytes += radhip_traversal_state_bytes(wave);
     al((void **)&s->d_req, (per_rank + 16) * 4, true);
     al((void **)&s->d_req_all, (size_t)world * (per_rank + 16) * 4, true);
     al((void **)&s->d_out, (size_t)world * per_rank * 4, true);
     al((void **)&s->d_in, per_rank * 4, true);
     al((void **)&s->d_queries, (size_t)world * nq * idx->row_stride, false);
     al((void **)&s->d_qpop, (size_t)world * nq * 4, false);
-    if (flags & RADHIP_TRAV_LOG_POPS) {
+    if (!wave && (flags & RADHIP_TRAV_LOG_POPS)) {
         P.poplog_cap = heap_cap;
         al((void **)&P.poplog_nodes, (size_t)nq * heap_cap * 4, false);
         al((void **)&P.poplog_levels, (size_t)nq * heap_cap, false);
@@ -417,12 +454,13 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
             rc = RADHIP_E_HIP;
         }
     }
-    if (rc != RADHIP_OK) { radhip_shard_destroy(s); return rc; }
+    if (rc != RADHIP_OK) { lk.unlock(); radhip_shard_destroy(s); return rc; }
     P.req = s->d_req; P.scores_in = s->d_in;
+    if (wave) rh_trav_bind_shard(wave, s->d_req, s->d_in, W, P.max_inner);
     EvalParams &E = s->E;
     E.fp = idx->d_fp + (row_first - idx->shard_first) * idx->lpr;
     E.first = row_first; E.count = row_count; E.queries = s->d_queries; E.qpop = s->d_qpop;
-    E.req_all = s->d_req_all; E.out = s->d_out; E.world = (uint32_t)world; E.nq = nq; E.W = W;
+    E.req_all = s->d_req_all; E.out = s->d_out; E.live = s->d_req + per_rank; E.world = (uint32_t)world; E.nq = nq; E.W = W;
     *out = s;
     return RADHIP_OK;
 }
@@ -432,6 +470,7 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
 extern "C" int radhip_shard_reset(radhip_shard_t *s, const uint8_t *queries_all) {
     if (!s || !queries_all) RH_FAIL(RADHIP_E_INVALID, "null argument");
     radhip_index *idx = s->idx;
+    if (s->wave) RH_TRY(radhip_traversal_reset(s->wave, queries_all + (size_t)s->rank * s->nq * idx->row_bytes));   // (own lock, own generation check)
     std::lock_guard<std::mutex> lk(idx->mu);
     if (s->graph_gen != idx->graph_gen)
         RH_FAIL(RADHIP_E_STATE, "the index changed since this sharded traversal was created: create a new one");
@@ -448,9 +487,11 @@ extern "C" int radhip_shard_reset(radhip_shard_t *s, const uint8_t *queries_all)
     hipStream_t st = idx->stream;
     RH_HIP(hipMemcpyAsync(s->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, st));
     RH_HIP(hipMemcpyAsync(s->d_qpop, pop.data(), tq * 4, hipMemcpyHostToDevice, st));
-    RH_HIP(hipMemsetAsync(s->P.hdr, 0, (size_t)s->nq * sizeof(ShardHeader), st));
-    RH_HIP(hipMemsetAsync(s->P.vis, 0, ((size_t)s->nq << s->P.vlog2) * 8, st));
-    RH_HIP(hipMemsetAsync(s->P.sc, 0, ((size_t)s->nq << s->P.slog2) * 8, st));
+    if (!s->wave) {
+        RH_HIP(hipMemsetAsync(s->P.hdr, 0, (size_t)s->nq * sizeof(ShardHeader), st));
+        RH_HIP(hipMemsetAsync(s->P.vis, 0, ((size_t)s->nq << s->P.vlog2) * 8, st));
+        RH_HIP(hipMemsetAsync(s->P.sc, 0, ((size_t)s->nq << s->P.slog2) * 8, st));
+    }
     RH_HIP(hipMemsetAsync(s->d_req, 0, (per_rank + 16) * 4, st));
     RH_HIP(hipMemsetAsync(s->d_in, 0, per_rank * 4, st));
     RH_HIP(hipStreamSynchronize(st));
@@ -459,6 +500,7 @@ extern "C" int radhip_shard_reset(radhip_shard_t *s, const uint8_t *queries_all)
 }
 
 extern "C" uint32_t radhip_shard_width(const radhip_shard_t *s) { return s ? s->W : 0; }
+extern "C" int radhip_shard_engine(const radhip_shard_t *s) { return s && s->wave ? 1 : 0; }
 extern "C" uint64_t radhip_shard_state_bytes(const radhip_shard_t *s) { return s ? s->state_bytes : 0; }
 
 static int shard_check(radhip_shard *s) {
@@ -469,8 +511,10 @@ static int shard_check(radhip_shard *s) {
 }
 
 // enqueue one step kernel on the index's stream (no synchronisation)
-static int shard_enqueue_step(radhip_shard *s) {
-    RH_HIP(hipMemsetAsync(s->d_req + (size_t)s->nq * s->W, 0, 64, s->idx->stream));
+static int shard_enqueue_step(radhip_shard *s, bool zero_live) {
+    // (in the product loop the evaluation kernel of the step before has zeroed the live count: one launch less)
+    if (zero_live) RH_HIP(hipMemsetAsync(s->d_req + (size_t)s->nq * s->W, 0, 64, s->idx->stream));
+    if (s->wave) return rh_trav_enqueue_shard_step(s->wave);
     hipLaunchKernelGGL(shard_step_kernel, dim3((s->nq + 63u) / 64u), dim3(64), 0, s->idx->stream, s->P);
     RH_HIP(hipGetLastError());
     return RADHIP_OK;
@@ -498,7 +542,7 @@ extern "C" int radhip_shard_step(radhip_shard_t *s, uint32_t *out_live) {
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_TRY(shard_check(s));
     RH_HIP(hipEventRecord(s->ev0, s->idx->stream));
-    RH_TRY(shard_enqueue_step(s));
+    RH_TRY(shard_enqueue_step(s, true));
     RH_HIP(hipEventRecord(s->ev1, s->idx->stream));
     uint32_t live = 0;
     RH_HIP(hipMemcpyAsync(&live, s->d_req + (size_t)s->nq * s->W, 4, hipMemcpyDeviceToHost, s->idx->stream));
@@ -552,11 +596,13 @@ extern "C" int radhip_shard_set_scores_in(radhip_shard_t *s, const uint32_t *hos
     return RADHIP_OK;
 }
 
+static int shard_first_error(radhip_shard *s);
+
 // ---- the product loop: kernels and RCCL collectives on one stream, device buffers end to end ------------
 extern "C" int radhip_shard_run(radhip_shard_t *s, radhip_comm_t *comm, uint64_t max_steps, uint64_t *out_steps) {
     if (!s || !comm) RH_FAIL(RADHIP_E_INVALID, "null argument");
     if (comm->world != s->world || comm->rank != s->rank) RH_FAIL(RADHIP_E_INVALID, "communicator and shard disagree on rank / world");
-    std::lock_guard<std::mutex> lk(s->idx->mu);
+    std::unique_lock<std::mutex> lk(s->idx->mu);
     RH_TRY(shard_check(s));
     hipStream_t st = s->idx->stream;
     const size_t per_rank = (size_t)s->nq * s->W;
@@ -570,7 +616,7 @@ extern "C" int radhip_shard_run(radhip_shard_t *s, radhip_comm_t *comm, uint64_t
     RH_HIP(hipEventRecord(s->ev0, st));
     for (;;) {
         if (phases) (void)hipEventRecord(pe[0], st);
-        RH_TRY(shard_enqueue_step(s));
+        RH_TRY(shard_enqueue_step(s, steps == 0));
         if (phases) (void)hipEventRecord(pe[1], st);
         RH_TRY(rh_comm_allgather_dev(comm, s->d_req, s->d_req_all, per_rank + 16, st));
         if (phases) (void)hipEventRecord(pe[2], st);
@@ -578,16 +624,22 @@ extern "C" int radhip_shard_run(radhip_shard_t *s, radhip_comm_t *comm, uint64_t
         if (phases) (void)hipEventRecord(pe[3], st);
         RH_TRY(rh_comm_reduce_scatter_u32_dev(comm, s->d_out, s->d_in, per_rank, st));
         if (phases) (void)hipEventRecord(pe[4], st);
-        // the live counts of all ranks travel behind the candidates: every rank stops at the same step
+        steps++;
+        s->exchanged_bytes += (uint64_t)s->world * (per_rank + 16) * 4 + (uint64_t)s->world * per_rank * 4;
+        // The live counts of all ranks travel behind the candidates, so every rank sees the same numbers and stops
+        // at the same step.  The host looks at them (a stream synchronisation) only every fourth step — and every
+        // 64th while no traversal can have reached n_to_score yet (a step scores W nodes at most): a step of
+        // finished traversals is a no-op, so looking late costs a few empty steps, never a different result.
+        const bool last = max_steps && steps >= max_steps;
+        const bool look = phases || last || (steps % (steps * s->W < s->n_to_score ? 64u : 4u)) == 0u;
+        if (!look) continue;
         for (int r = 0; r < s->world; ++r)
             RH_HIP(hipMemcpyAsync(&live[r], s->d_req_all + (size_t)r * (per_rank + 16) + per_rank, 4, hipMemcpyDeviceToHost, st));
         RH_HIP(hipStreamSynchronize(st));
         if (phases) for (int i = 0; i < 4; ++i) { float m = 0.f; if (hipEventElapsedTime(&m, pe[i], pe[i + 1]) == hipSuccess) pms[i] += m; }
-        steps++;
-        s->exchanged_bytes += (uint64_t)s->world * (per_rank + 16) * 4 + (uint64_t)s->world * per_rank * 4;
         uint64_t tot = 0;
         for (int r = 0; r < s->world; ++r) tot += live[r];
-        if (tot == 0 || (max_steps && steps >= max_steps)) break;
+        if (tot == 0 || last) break;
     }
     RH_HIP(hipEventRecord(s->ev1, st));
     RH_HIP(hipStreamSynchronize(st));
@@ -600,7 +652,20 @@ extern "C" int radhip_shard_run(radhip_shard_t *s, radhip_comm_t *comm, uint64_t
     }
     s->steps += steps;
     if (out_steps) *out_steps = steps;
-    // a device-side failure of any local traversal is an error of the call
+    lk.unlock();
+    return shard_first_error(s);
+}
+
+// a device-side failure of any local traversal is an error of the call
+static int shard_first_error(radhip_shard *s) {
+    if (s->wave) {
+        std::vector<radhip_trav_stats_t> st(s->nq);
+        RH_TRY(radhip_traversal_stats(s->wave, st.data()));
+        for (uint32_t i = 0; i < s->nq; ++i)
+            if (st[i].status < 0) RH_FAIL(st[i].status, "sharded traversal %u overflowed a fixed-capacity device structure (status %d); "
+                                          "RADHIP_SHARD_ENGINE=thread sizes its queue for the whole graph", i, st[i].status);
+        return RADHIP_OK;
+    }
     std::vector<ShardHeader> hdr(s->nq);
     RH_HIP(hipMemcpy(hdr.data(), s->P.hdr, (size_t)s->nq * sizeof(ShardHeader), hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < s->nq; ++i)
@@ -610,6 +675,7 @@ extern "C" int radhip_shard_run(radhip_shard_t *s, radhip_comm_t *comm, uint64_t
 
 extern "C" int radhip_shard_stats(const radhip_shard_t *s, radhip_trav_stats_t *out) {
     if (!s || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (s->wave) return radhip_traversal_stats(s->wave, out);
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_HIP(hipSetDevice(s->idx->device));
     std::vector<ShardHeader> hdr(s->nq);
@@ -625,6 +691,7 @@ extern "C" int radhip_shard_results(const radhip_shard_t *s, uint32_t q, uint32_
                                     uint32_t *out_or, uint64_t cap, uint64_t *out_n) {
     if (!s || !out_n) RH_FAIL(RADHIP_E_INVALID, "null argument");
     if (q >= s->nq) RH_FAIL(RADHIP_E_RANGE, "traversal %u out of range", q);
+    if (s->wave) return radhip_traversal_results(s->wave, q, out_slots, out_and, out_or, cap, out_n);
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_HIP(hipSetDevice(s->idx->device));
     ShardHeader h;
@@ -646,6 +713,7 @@ extern "C" int radhip_shard_pop_log(const radhip_shard_t *s, uint32_t q, uint32_
                                     uint64_t cap, uint64_t *out_n) {
     if (!s || !out_n) RH_FAIL(RADHIP_E_INVALID, "null argument");
     if (q >= s->nq) RH_FAIL(RADHIP_E_RANGE, "traversal %u out of range", q);
+    if (s->wave) return radhip_traversal_pop_log(s->wave, q, out_nodes, out_levels, cap, out_n);
     if (!s->P.poplog_nodes) RH_FAIL(RADHIP_E_STATE, "sharded traversal was created without RADHIP_TRAV_LOG_POPS");
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_HIP(hipSetDevice(s->idx->device));

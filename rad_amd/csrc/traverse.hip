@@ -77,6 +77,8 @@ struct TravHeader {
     // [mid_pos, mid_end) of the key pool; the far runs hold keys >= mid_limit only
     uint64_t mid_limit, far_min;
     uint32_t mid_end, n_remid;
+    // row-sharded form of trav4_kernel: candidates out (count | level << 8 | lane rotation << 16), entry points primed
+    uint32_t sh_pend, sh_prime_at;
 };
 
 struct TravParams {
@@ -114,6 +116,11 @@ struct TravParams {
     uint8_t *poplog_levels;
     uint64_t poplog_cap;
     unsigned long long *prof;   // RH_PROFILE builds only: per-section cycle sums
+    // row-sharded form (trav4_kernel<LPR, false, true>, shard.hip): candidate slots out, packed counts in
+    uint32_t *sh_req;              // [nq * sh_W + 16]: this step's candidates (NO_SLOT padded), then the live count
+    const uint32_t *sh_in;         // [nq * sh_W]: and | or << 16 of the last step's candidates
+    uint32_t *sh_pend_h;           // [nq * 16]: the table bucket every candidate out has claimed
+    uint32_t sh_W;
 };
 
 __device__ __forceinline__ unsigned long long ld64(const unsigned long long *p) {
@@ -664,6 +671,7 @@ struct radhip_traversal {
     bool fresh_tables = true;   // tables not cleared yet (first upload)
     bool use4 = false;   // trav4_kernel (four traversals per wave) when every adjacency row is <= 16 wide
     bool use_gt = false; // grouped visited/scored table (needs the index's graph-locality layout)
+    bool sharded = false; // the row-sharded form of trav4_kernel (shard.hip): stepped, never run()
     size_t gt_bytes = 0;
     uint64_t graph_gen = 0;   // generation of the index this state was sized for
     std::vector<uint8_t> h_queries;   // host copy: the grouped table's overflow fallback re-arms the batch itself
@@ -732,6 +740,7 @@ extern "C" int radhip_traversal_destroy(radhip_traversal_t *t) {
     if (t->P.rhead) (void)hipFree(t->P.rhead);
     if (t->P.midpool) (void)hipFree(t->P.midpool);
     if (t->P.r_save) (void)hipFree(t->P.r_save);
+    if (t->P.sh_pend_h) (void)hipFree(t->P.sh_pend_h);
     if (t->P.poplog_nodes) (void)hipFree(t->P.poplog_nodes);
     if (t->P.poplog_levels) (void)hipFree(t->P.poplog_levels);
     if (t->ev0) (void)hipEventDestroy(t->ev0);
@@ -744,15 +753,17 @@ static bool trav4_shape_ok(const radhip_index *idx);
 static int trav_forced_kernel();
 static int trav_capacity_of(radhip_index *idx, bool use4, uint32_t *out);
 
-extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queries, uint32_t nq,
-                                       uint64_t n_to_score, uint32_t flags, radhip_traversal_t **out) {
+static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_t nq, uint64_t n_to_score, uint32_t flags,
+                            bool sharded, radhip_traversal_t **out) {
     if (!idx || !queries || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
     if (nq == 0) RH_FAIL(RADHIP_E_INVALID, "nq must be > 0");
     if (n_to_score == 0) RH_FAIL(RADHIP_E_INVALID, "n_to_score must be > 0");
     if (!idx->has_vectors || !idx->has_graph) RH_FAIL(RADHIP_E_STATE, "index needs vectors and a graph");
-    RH_REQUIRE_FULL_CORPUS(idx);
-    if (idx->g_n > idx->n) RH_FAIL(RADHIP_E_STATE, "graph has more nodes (%llu) than the corpus has rows (%llu)",
-                                   (unsigned long long)idx->g_n, (unsigned long long)idx->n);
+    if (!sharded) {   // (the sharded form never reads a fingerprint: the rows may be another rank's)
+        RH_REQUIRE_FULL_CORPUS(idx);
+        if (idx->g_n > idx->n) RH_FAIL(RADHIP_E_STATE, "graph has more nodes (%llu) than the corpus has rows (%llu)",
+                                       (unsigned long long)idx->g_n, (unsigned long long)idx->n);
+    }
     if (idx->g_n > 1000000000ull) RH_FAIL(RADHIP_E_INVALID, "RAD traversal needs slots < 1e9");
     std::lock_guard<std::mutex> lk(idx->mu);
     RH_TRY(rh_ensure_device(idx));
@@ -763,8 +774,11 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     }
     radhip_traversal *t = new (std::nothrow) radhip_traversal();
     if (!t) RH_FAIL(RADHIP_E_NOMEM, "out of host memory");
-    t->idx = idx; t->nq = nq; t->n_to_score = n_to_score; t->flags = flags;
-    {
+    t->idx = idx; t->nq = nq; t->n_to_score = n_to_score; t->flags = flags; t->sharded = sharded;
+    if (sharded) {
+        if (!trav4_shape_ok(idx)) { delete t; RH_FAIL(RADHIP_E_INVALID, "the wave engine needs adjacency rows of at most 16 slots"); }
+        t->use4 = true;
+    } else {
         const int forced = trav_forced_kernel();
         t->use4 = trav4_shape_ok(idx) && forced != 1;
         if (t->use4 && forced != 4) {   // auto: four per wave only beyond two resident rounds of trav_kernel
@@ -816,7 +830,7 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
         const char *e = getenv("RADHIP_TABLE");
         const bool force_group = e && e[0] == 'g';
         const uint32_t gt_log2 = std::max<uint32_t>(7, log2_ceil((scored_cap * 5 + 31) / 32));
-        const bool can = idx->layout_valid && idx->d_adjx0 && t->use4 && gt_log2 <= 17;
+        const bool can = idx->layout_valid && idx->d_adjx0 && t->use4 && gt_log2 <= 17 && !sharded;
         t->use_gt = can && force_group;
         P.gt_log2 = gt_log2;
         P.adjx0 = idx->d_adjx0; P.adjxU = idx->d_adjxU; P.topx = idx->d_topx; P.lid = idx->d_lid;
@@ -855,6 +869,7 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     if (rc == 0) RH_A(P.rhead, t->rhead_bytes);
     if (rc == 0) RH_A(P.midpool, (size_t)nq * 256 * 8);
     if (rc == 0) RH_A(P.r_save, t->rsave_bytes);
+    if (rc == 0 && sharded) RH_A(P.sh_pend_h, (size_t)nq * 16 * 4);
     if (rc == 0 && (flags & RADHIP_TRAV_LOG_POPS)) {
         P.poplog_cap = pq_cap;
         RH_A(P.poplog_nodes, (size_t)nq * P.poplog_cap * 4);
@@ -870,6 +885,32 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
     *out = t;
     return RADHIP_OK;
 }
+
+extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queries, uint32_t nq,
+                                       uint64_t n_to_score, uint32_t flags, radhip_traversal_t **out) {
+    return trav_create_impl(idx, queries, nq, n_to_score, flags, false, out);
+}
+
+// ---- the row-sharded form (shard.hip owns the exchange buffers and the loop) ---------------------------------
+int rh_trav_create_sharded(radhip_index *idx, const uint8_t *queries, uint32_t nq, uint64_t n_to_score, uint32_t flags,
+                           radhip_traversal **out) {
+    return trav_create_impl(idx, queries, nq, n_to_score, flags, true, out);
+}
+void rh_trav_bind_shard(radhip_traversal *t, uint32_t *d_req, const uint32_t *d_in, uint32_t W, uint32_t max_inner) {
+    t->P.sh_req = d_req; t->P.sh_in = d_in; t->P.sh_W = W; t->P.max_pops = max_inner;
+}
+// one frontier step of every local traversal, enqueued on the index's stream (no synchronisation; caller holds idx->mu)
+int rh_trav_enqueue_shard_step(radhip_traversal *t) {
+    radhip_index *idx = t->idx;
+    if (!t->sharded || !t->P.sh_req) RH_FAIL(RADHIP_E_STATE, "not a sharded traversal");
+    const uint32_t grid = (t->nq + 3u) / 4u;
+    // (the fingerprint width only matters to the gather, which this form does not have: one instantiation)
+    hipLaunchKernelGGL((trav4_kernel<8, false, true>), dim3(grid), dim3(64), 0, idx->stream, t->P);
+    RH_HIP(hipGetLastError());
+    t->launches++;
+    return RADHIP_OK;
+}
+uint64_t rh_trav_graph_gen(const radhip_traversal *t) { return t->graph_gen; }
 
 extern "C" int radhip_traversal_reset(radhip_traversal_t *t, const uint8_t *queries) {
     if (!t || !queries) RH_FAIL(RADHIP_E_INVALID, "null argument");
@@ -996,6 +1037,7 @@ extern "C" int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, ui
     // traversal object does not survive an add() / load_graph() (the kernel would read freed arrays)
     if (t->graph_gen != idx->graph_gen)
         RH_FAIL(RADHIP_E_STATE, "the index changed since this traversal object was created: create a new one");
+    if (t->sharded) RH_FAIL(RADHIP_E_STATE, "a sharded traversal is stepped by radhip_shard_run / radhip_shard_step");
     t->P.max_pops = max_pops;
     const bool first_launch = t->launches == 0;
     std::vector<TravHeader> hdr(t->nq);

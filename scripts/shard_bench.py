@@ -23,7 +23,7 @@ del X
 ref = DeviceTraversal(idx, Q[:256], nts); ref.run(); want = ref.stats(); ref.close()
 comm = RcclComm(0, 1, RcclComm.unique_id(), 0)
 sh = DeviceShard(idx, 0, 1, 0, n, Q, nts)
-print(f"state {sh.state_bytes() / 2**30:.1f} GiB", flush=True)
+print(f"engine {sh.engine}, state {sh.state_bytes() / 2**30:.1f} GiB", flush=True)
 for rep in range(2):
     if rep: sh.reset(Q)
     t0 = time.perf_counter(); steps = sh.run(comm); dt = time.perf_counter() - t0

@@ -143,8 +143,16 @@ def _row_sharded_setup(oracle, n, nts, world, nq, mode=2, seed=7):
     return X, g, full, Qall
 
 
+@pytest.fixture(params=["wave", "thread"])
+def engine(request, monkeypatch):
+    """both step kernels of shard.hip: the single-GPU traversal kernel cut at the fingerprint read, and the
+    thread-per-traversal restatement of the oracle's stepper"""
+    monkeypatch.setenv("RADHIP_SHARD_ENGINE", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("world", [2, 3])
-def test_row_sharded_equals_single_gpu_traversal(gpu, oracle, world):
+def test_row_sharded_equals_single_gpu_traversal(gpu, oracle, world, engine):
     """`world` ranks' worth of step / evaluation kernels on one GPU, each rank keeping ONLY its rows
     (radhip_index_keep_rows): every query's scored order, counts and pop log equal the oracle's traversal of
     the whole corpus, and the single-GPU kernel's."""
@@ -166,6 +174,7 @@ def test_row_sharded_equals_single_gpu_traversal(gpu, oracle, world):
         assert idx.info().has_vectors
         idxs.append(idx)
         shards.append(DeviceShard(idx, r, world, first, count, Qall, nts, log_pops=True))
+        assert shards[-1].engine == engine
     steps = _lockstep(shards)
     assert steps > 10
     for r in range(world):
@@ -184,7 +193,7 @@ def test_row_sharded_equals_single_gpu_traversal(gpu, oracle, world):
             assert st.n_pops[q] == want.n_pops and st.n_nbr[q] == want.n_nbr
 
 
-def test_row_sharded_native_loop_world1_rccl(gpu, oracle):
+def test_row_sharded_native_loop_world1_rccl(gpu, oracle, engine):
     """radhip_shard_run — the product loop (kernels + RCCL collectives on one stream, device buffers) — with
     a real RCCL communicator of world 1, to a drained queue (n_to_score = n)."""
     from rad_amd.device import DeviceShard, RcclComm
@@ -192,6 +201,7 @@ def test_row_sharded_native_loop_world1_rccl(gpu, oracle):
     X, g, full, Qall = _row_sharded_setup(oracle, n, n, 1, nq, mode=1, seed=4)
     comm = RcclComm(0, 1, RcclComm.unique_id(), 0)
     sh = DeviceShard(full, 0, 1, 0, n, Qall, n, log_pops=True)
+    assert sh.engine == engine
     steps = sh.run(comm)
     assert steps > 10
     for q in range(nq):

@@ -926,8 +926,8 @@ static int trav_launch(radhip_traversal *t) {
     radhip_index *idx = t->idx;
 #ifdef RH_PROFILE
     static unsigned long long *d_prof = nullptr;
-    if (!d_prof) { (void)hipMalloc((void **)&d_prof, 80); }
-    (void)hipMemset(d_prof, 0, 80);
+    if (!d_prof) { (void)hipMalloc((void **)&d_prof, 208); }
+    (void)hipMemset(d_prof, 0, 208);
     t->P.prof = d_prof;
 #else
     t->P.prof = nullptr;
@@ -958,13 +958,25 @@ static int trav_launch(radhip_traversal *t) {
     RH_HIP(hipEventElapsedTime(&ms, t->ev0, t->ev1));
 #ifdef RH_PROFILE
     {
-        unsigned long long hp[10];
-        (void)hipMemcpy(hp, t->P.prof, 80, hipMemcpyDeviceToHost);
-        unsigned long long tot = 0; for (int i = 0; i < 10; ++i) tot += hp[i];
-        const char *nm[10] = {"loophead", "flush", "pop+repivot", "decode+adj", "probe", "eval", "finish+enqueue", "old+descent-pre", "", ""};
+        unsigned long long hp[26];
+        (void)hipMemcpy(hp, t->P.prof, 208, hipMemcpyDeviceToHost);
+        unsigned long long tot = 0; for (int i = 0; i < 9; ++i) tot += hp[i];
+        const char *nm[10] = {"loophead", "flush", "pop", "decode+adj", "probe", "eval", "finish+enqueue", "old+descent-pre", "repivot", ""};
         fprintf(stderr, "[prof] total %llu cycles:", tot);
-        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * hp[i] / (tot ? tot : 1));
-        fprintf(stderr, "\n");
+        for (int i = 0; i < 9; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * hp[i] / (tot ? tot : 1));
+        fprintf(stderr, "; %llu re-pivot events of a wavefront, %.0f cycles each\n", hp[9], hp[9] ? (double)hp[8] / hp[9] : 0.0);
+        {   // inside the re-pivot (these sections are part of "repivot" above, whose own slot holds what is left)
+            const char *n2[8] = {"lo-scan", "remid", "pivot-choice", "stg-scan", "squeeze", "mid-loop", "extract-tail", "dry+tail"};
+            unsigned long long t2 = hp[8]; for (int i = 10; i < 18; ++i) t2 += hp[i];
+            for (int i = 20; i < 25; ++i) t2 += hp[i];
+            fprintf(stderr, "[prof] inside the re-mids (cycles per call): pre-flush %.0f, demote %.0f, scan+collect %.0f, settle %.0f, sort+mid run %.0f, tail %.0f; far runs at a re-mid %.0f\n",
+                    (double)hp[20] / (hp[18] ? hp[18] : 1), (double)hp[21] / (hp[18] ? hp[18] : 1), (double)hp[22] / (hp[18] ? hp[18] : 1),
+                    (double)hp[23] / (hp[18] ? hp[18] : 1), (double)hp[24] / (hp[18] ? hp[18] : 1), (double)hp[11] / (hp[18] ? hp[18] : 1),
+                    (double)hp[25] / (hp[18] ? hp[18] : 1));
+            fprintf(stderr, "[prof] re-pivot %.1f%% of all:", 100.0 * t2 / ((tot - hp[8] + t2) ? (tot - hp[8] + t2) : 1));
+            for (int i = 10; i < 18; ++i) fprintf(stderr, " %s=%.1f%%", n2[i - 10], 100.0 * hp[i] / (t2 ? t2 : 1));
+            fprintf(stderr, " rest=%.1f%%; %llu re-mid calls of a wavefront for %llu rows\n", 100.0 * hp[8] / (t2 ? t2 : 1), hp[18], hp[19]);
+        }
     }
 #endif
     t->kernel_ms += ms;

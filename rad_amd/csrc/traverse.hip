@@ -147,7 +147,42 @@ __device__ __forceinline__ void st_relaxed(uint32_t *p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Decimal tables of the queue key (the member string "{node}:{level}" is kept as a zero-padded decimal).  A select
+// chain or comparison tree over a per-lane value compiles to a tree of exec-mask branches, ~50 scalar instructions
+// per use; a table read from LDS is one.
+struct KeyTabs {
+    uint32_t pow10[16];      // 10^e, e = 0..9
+    uint2 div10[16];         // {m, s}: n / 10^e == umulhi(n, m) >> s for n < 2^30, e = 1..9
+};
+__device__ __forceinline__ void keytabs_init(KeyTabs &T, uint32_t lane) {   // lanes 0..15 of a wavefront; sync before use
+    if (lane < 16u) {
+        uint32_t p = 1u;
+        for (uint32_t i = 0; i < lane && i < 9u; ++i) p *= 10u;
+        T.pow10[lane] = p;
+        uint32_t l = 0;
+        while ((1u << l) < p) l++;
+        // m = floor(2^(30+l) / p) + 1 < 2^32; exact for n < 2^30 because 2^l > p (p is not a power of two for e >= 1)
+        T.div10[lane] = lane == 0u ? make_uint2(0u, 0u) : make_uint2((uint32_t)(((1ull << (30u + l)) / p) + 1ull), l - 2u);
+    }
+}
+// slot of a key: (p + 1) / 10^dl - 1
+__device__ __forceinline__ uint32_t key_slot_tab(const KeyTabs &T, unsigned long long key) {
+    const uint32_t n = ((uint32_t)(key >> 8) & 0x3FFFFFFFu) + 1u, e = (uint32_t)(key >> 4) & 0xFu;
+    const uint2 ms = T.div10[e];
+    return (e ? (__umulhi(n, ms.x) >> ms.y) : n) - 1u;
+}
+// rh_make_key (common.h): digits = floor(log10) estimate from the bit length, one compare to fix it
+__device__ __forceinline__ unsigned long long make_key_tab(const KeyTabs &T, uint32_t q24, uint32_t slot, uint32_t level) {
+    const uint32_t bits = 32u - (uint32_t)__clz((int)(slot | 1u));
+    const uint32_t t = (bits * 1233u) >> 12;                    // digits - 1 or digits
+    const uint32_t d = t + ((slot | 1u) >= T.pow10[t] ? 1u : 0u);
+    const uint32_t dl = 9u - d;
+    const uint32_t p = (slot + 1u) * T.pow10[dl] - 1u;
+    return ((unsigned long long)q24 << 38) | ((unsigned long long)p << 8) | ((unsigned long long)dl << 4) | (unsigned long long)rh_level_rank(level);
+}
+
 struct TravLds {
+    KeyTabs kt;
     unsigned long long stg[S_CAP];
     uint32_t new_slot[64];
     uint32_t new_h[64];
@@ -242,6 +277,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
         k0 = rs[lane]; k1 = rs[64 + lane]; k2 = rs[128 + lane]; k3 = rs[192 + lane];
     }
     for (uint32_t i = lane; i < cnt; i += 64) L.stg[i] = P.stg_save[(uint64_t)q * S_CAP + i];
+    keytabs_init(L.kt, lane);
     WSYNC();
 
     // ---- far: append keys (one per lane where `has`) to staging ----------------
@@ -446,7 +482,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
                 __hip_atomic_store(&ht[L.new_h[ni]], (unsigned long long)s2 | ((unsigned long long)(a | (o << 12) | (level == 0 ? VAL_V0 : 0u) | (P.epoch << VAL_EPOCH_SHIFT)) << 32),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 scored[n_scored + ni] = make_uint2(s2, a | (o << 16));
-                key = rh_make_key_dev(rh_q24_dev(a, o), s2, level);
+                key = make_key_tab(L.kt, rh_q24_dev(a, o), s2, level);
             }
             n_scored += nn;
             enqueue(mine, key);
@@ -454,7 +490,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
         if (isnew) L.claimtab[ci] = 0u;   // entries are stored: the claims are spent
         if (__ballot(push_old)) {
             unsigned long long key = RH_KEY_INF;
-            if (push_old) key = rh_make_key_dev(rh_q24_dev(val & 0xFFFu, (val >> 12) & 0xFFFu), slot, level);
+            if (push_old) key = make_key_tab(L.kt, rh_q24_dev(val & 0xFFFu, (val >> 12) & 0xFFFu), slot, level);
             enqueue(push_old, key);
         }
     };
@@ -539,7 +575,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
                 __hip_atomic_store(&ht[L.new_h[j]], (unsigned long long)s2 | ((unsigned long long)(a | (o << 12) | (level == 0 ? VAL_V0 : 0u) | (P.epoch << VAL_EPOCH_SHIFT)) << 32),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 scored[n_scored + rk] = make_uint2(s2, a | (o << 16));
-                key = rh_make_key_dev(rh_q24_dev(a, o), s2, level);
+                key = make_key_tab(L.kt, rh_q24_dev(a, o), s2, level);
             }
             n_scored += nn;
             enqueue(mine, key);
@@ -547,7 +583,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
         if (isnew) L.claimtab[ci] = 0u;
         if (__ballot(push_old)) {
             unsigned long long key = RH_KEY_INF;
-            if (push_old) key = rh_make_key_dev(rh_q24_dev(val & 0xFFFu, (val >> 12) & 0xFFFu), slot, level);
+            if (push_old) key = make_key_tab(L.kt, rh_q24_dev(val & 0xFFFu, (val >> 12) & 0xFFFu), slot, level);
             enqueue(push_old, key);
         }
         WSYNC();
@@ -585,7 +621,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
         }
         const int win = __ffsll((unsigned long long)__ballot(k0 == mk)) - 1;
         if ((int)lane == win) { k0 = k1; k1 = k2; k2 = k3; k3 = RH_KEY_INF; }
-        const uint32_t node = key_slot(mk);
+        const uint32_t node = key_slot_tab(L.kt, mk);
         const uint32_t level = rh_rank_level((uint32_t)mk & 0xFu);
         if (P.poplog_nodes && n_pops < P.poplog_cap && lane == 0) {
             P.poplog_nodes[(uint64_t)q * P.poplog_cap + n_pops] = node;
@@ -631,7 +667,7 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
             const bool any0 = __ballot(push0) != 0;
             if (any0) {
                 if (nl > 0) n_upper++;
-                enqueue(push0, rh_make_key_dev((uint32_t)(mk >> 38), node, nl));
+                enqueue(push0, make_key_tab(L.kt, (uint32_t)(mk >> 38), node, nl));
             }
         }
     }

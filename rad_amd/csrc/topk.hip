@@ -55,6 +55,20 @@ __device__ __forceinline__ void tk_append(unsigned long long *buf, uint32_t &cnt
     }
 }
 
+// Sum of p[u] over the 8 lanes of a row FOR EIGHT VALUES AT ONCE, transposed: lane c of the row ends up with the
+// row total of p[c].  A butterfly that halves the values a lane carries at every step (partner lane c ^ 7, c ^ 3,
+// c ^ 1: half-row mirror and quad permutes) costs 4 + 2 + 1 exchanges instead of the 8 x 3 of eight full
+// reductions — the kernel is VALU-bound (profiles/r02/README.md §7).
+__device__ __forceinline__ uint32_t tk_transpose_sum8(const uint32_t (&p)[8], bool b2, bool b1, bool b0) {
+    uint32_t t[4], s[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint32_t keep = b2 ? p[j + 4] : p[j], send = b2 ? p[j] : p[j + 4]; t[j] = keep + rh_dpp<RH_DPP_ROW_HALF_MIRROR>(send); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const uint32_t keep = b1 ? t[j + 2] : t[j], send = b1 ? t[j] : t[j + 2]; s[j] = keep + rh_dpp<0x1B>(send); }   // quad_perm:[3,2,1,0]
+    const uint32_t keep = b0 ? s[1] : s[0], send = b0 ? s[0] : s[1];
+    return keep + rh_dpp<RH_DPP_QUAD_XOR1>(send);
+}
+
 template <int LPR, int NQ>
 __global__ __launch_bounds__(256) void topk_scan_kernel(const uint4 *__restrict__ fp, uint64_t first, uint64_t count,
                                                         const uint4 *__restrict__ queries, const uint32_t *__restrict__ qpop,
@@ -93,14 +107,28 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const uint4 *__restrict_
                 v[u] = make_uint4(0, 0, 0, 0);
                 if (r < count) v[u] = fp[(first + r) * LPR + chunk];
             }
+            if constexpr (LPR == 8) {   // (one batch per tile: b0 == 0, lane c keeps row c of its group)
+                const bool b2 = (chunk & 4u) != 0u, b1 = (chunk & 2u) != 0u, b0c = (chunk & 1u) != 0u;
+                uint32_t p[8];
 #pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v[u]));
-                if ((int)chunk == b0 + u) keep_rp = rp;
+                for (int u = 0; u < 8; ++u) p[u] = rh_popc4(v[u]);
+                keep_rp = tk_transpose_sum8(p, b2, b1, b0c);
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) {
-                    const uint32_t a = rh_group_sum<LPR>(rh_popc4_and(v[u], q[i]));
-                    if ((int)chunk == b0 + u) keep_a[i] = a;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) p[u] = rh_popc4_and(v[u], q[i]);
+                    keep_a[i] = tk_transpose_sum8(p, b2, b1, b0c);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v[u]));
+                    if ((int)chunk == b0 + u) keep_rp = rp;
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) {
+                        const uint32_t a = rh_group_sum<LPR>(rh_popc4_and(v[u], q[i]));
+                        if ((int)chunk == b0 + u) keep_a[i] = a;
+                    }
                 }
             }
         }

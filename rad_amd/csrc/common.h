@@ -146,6 +146,20 @@ __device__ __forceinline__ uint32_t rh_group_sum(uint32_t v) {
     if (LPR >= 16) v += rh_dpp<RH_DPP_ROW_MIRROR>(v);
     return v;
 }
+// Sum of p[u] over the 8 lanes of a row FOR EIGHT VALUES AT ONCE, transposed: lane c of the row ends up with the
+// row total of p[c].  A butterfly that halves the values a lane carries at every step (partner lane c ^ 7, c ^ 3,
+// c ^ 1: half-row mirror and quad permutes) costs 4 + 2 + 1 exchanges instead of the 8 x 3 of eight full
+// reductions — the scan kernels are VALU-bound at 8 queries per pass (profiles/r02/README.md §7).
+__device__ __forceinline__ uint32_t rh_transpose_sum8(const uint32_t (&p)[8], bool b2, bool b1, bool b0) {
+    uint32_t t[4], s[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint32_t keep = b2 ? p[j + 4] : p[j], send = b2 ? p[j] : p[j + 4]; t[j] = keep + rh_dpp<RH_DPP_ROW_HALF_MIRROR>(send); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const uint32_t keep = b1 ? t[j + 2] : t[j], send = b1 ? t[j] : t[j + 2]; s[j] = keep + rh_dpp<0x1B>(send); }   // quad_perm:[3,2,1,0]
+    const uint32_t keep = b0 ? s[1] : s[0], send = b0 ? s[0] : s[1];
+    return keep + rh_dpp<RH_DPP_QUAD_XOR1>(send);
+}
+
 // wave-wide unsigned min, result uniform (read from lane 63 after a row scan + row broadcasts)
 __device__ __forceinline__ uint32_t rh_wave_min_u32(uint32_t v) {
 #define RH_MIN_STEP(CTRL, ROWMASK)                                                              \

@@ -55,20 +55,6 @@ __device__ __forceinline__ void tk_append(unsigned long long *buf, uint32_t &cnt
     }
 }
 
-// Sum of p[u] over the 8 lanes of a row FOR EIGHT VALUES AT ONCE, transposed: lane c of the row ends up with the
-// row total of p[c].  A butterfly that halves the values a lane carries at every step (partner lane c ^ 7, c ^ 3,
-// c ^ 1: half-row mirror and quad permutes) costs 4 + 2 + 1 exchanges instead of the 8 x 3 of eight full
-// reductions — the kernel is VALU-bound (profiles/r02/README.md §7).
-__device__ __forceinline__ uint32_t tk_transpose_sum8(const uint32_t (&p)[8], bool b2, bool b1, bool b0) {
-    uint32_t t[4], s[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const uint32_t keep = b2 ? p[j + 4] : p[j], send = b2 ? p[j] : p[j + 4]; t[j] = keep + rh_dpp<RH_DPP_ROW_HALF_MIRROR>(send); }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { const uint32_t keep = b1 ? t[j + 2] : t[j], send = b1 ? t[j] : t[j + 2]; s[j] = keep + rh_dpp<0x1B>(send); }   // quad_perm:[3,2,1,0]
-    const uint32_t keep = b0 ? s[1] : s[0], send = b0 ? s[0] : s[1];
-    return keep + rh_dpp<RH_DPP_QUAD_XOR1>(send);
-}
-
 template <int LPR, int NQ>
 __global__ __launch_bounds__(256) void topk_scan_kernel(const uint4 *__restrict__ fp, uint64_t first, uint64_t count,
                                                         const uint4 *__restrict__ queries, const uint32_t *__restrict__ qpop,
@@ -112,12 +98,12 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const uint4 *__restrict_
                 uint32_t p[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) p[u] = rh_popc4(v[u]);
-                keep_rp = tk_transpose_sum8(p, b2, b1, b0c);
+                keep_rp = rh_transpose_sum8(p, b2, b1, b0c);
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) p[u] = rh_popc4_and(v[u], q[i]);
-                    keep_a[i] = tk_transpose_sum8(p, b2, b1, b0c);
+                    keep_a[i] = rh_transpose_sum8(p, b2, b1, b0c);
                 }
             } else {
 #pragma unroll

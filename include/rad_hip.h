@@ -345,6 +345,12 @@ void radhip_rad_key_decode(uint64_t key, uint32_t *slot, uint32_t *level);
  * digit count) for n (and, or, slot, level) tuples */
 int radhip_debug_device_keys(radhip_index_t *idx, const uint32_t *and_cnt, const uint32_t *or_cnt,
                              const uint32_t *slot, const uint32_t *level, uint64_t n, uint64_t *out_keys);
+/* test hook: the traversal kernel's staging sort (one wavefront, keys in registers) on `batches` buffers of 256
+ * u64 slots each, counts[b] <= radhip_debug_staging_capacity() keys valid; out: the same layout, the first
+ * capacity slots of every buffer sorted ascending with all-ones behind the valid keys */
+int radhip_debug_sort_staging(radhip_index_t *idx, const uint64_t *keys, const uint32_t *counts, uint32_t batches,
+                              uint64_t *out);
+uint32_t radhip_debug_staging_capacity(void);
 
 #ifdef __cplusplus
 }

@@ -122,6 +122,8 @@ SIGNATURES = {
     "radhip_comm_world": (C.c_int, [_P]),
     "radhip_rad_key": (_U64, [_U32, _U32, _U32, _U32]),
     "radhip_debug_device_keys": (C.c_int, [_P, _P, _P, _P, _P, _U64, _P]),
+    "radhip_debug_sort_staging": (C.c_int, [_P, _P, _P, _U32, _P]),
+    "radhip_debug_staging_capacity": (_U32, []),
     "radhip_rad_key_decode": (None, [_U64, C.POINTER(_U32), C.POINTER(_U32)]),
 }
 

@@ -1200,11 +1200,60 @@ extern "C" int radhip_traversal_frontier(const radhip_traversal_t *t, uint64_t *
 }
 
 // ---- test hook: the device restatements of the queue key, evaluated on the GPU -------------
+// Both restatements must agree — the comparison-tree one of common.h (trav_kernel's prime path, other kernels) and
+// the table one the traversal kernels use — and the table decode must give the slot back; a disagreement shows up
+// as an all-ones key.
 __global__ void debug_keys_kernel(const uint32_t *a, const uint32_t *o, const uint32_t *slot, const uint32_t *level,
                                   uint64_t n, unsigned long long *out) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        out[i] = rh_make_key_dev(rh_q24_dev(a[i], o[i]), slot[i], level[i]);
+    __shared__ KeyTabs T;
+    keytabs_init(T, threadIdx.x);
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long k1 = rh_make_key_dev(rh_q24_dev(a[i], o[i]), slot[i], level[i]);
+        const unsigned long long k2 = make_key_tab(T, rh_q24_dev(a[i], o[i]), slot[i], level[i]);
+        out[i] = (k1 == k2 && key_slot_tab(T, k2) == slot[i]) ? k2 : ~0ull;
+    }
 }
+
+// test hook: trav4_kernel's staging sort (t4_sort256: register-resident flip-form bitonic network, one wavefront)
+__global__ __launch_bounds__(64) void debug_sort_kernel(const unsigned long long *in, const uint32_t *counts, unsigned long long *out) {
+    __shared__ unsigned long long S[256];
+    const uint32_t lane = threadIdx.x, n = counts[blockIdx.x];
+    for (uint32_t i = lane; i < 256u; i += 64u) S[i] = i < n ? in[(uint64_t)blockIdx.x * 256u + i] : 0x1234ull;   // junk beyond n: the sort must not read it
+    WSYNC();
+    t4_sort256(S, n, lane);
+    WSYNC();
+    for (uint32_t i = lane; i < T4_S; i += 64u) out[(uint64_t)blockIdx.x * 256u + i] = S[i];
+}
+
+extern "C" int radhip_debug_sort_staging(radhip_index_t *idx, const uint64_t *keys, const uint32_t *counts, uint32_t batches,
+                                         uint64_t *out) {
+    if (!idx || !keys || !counts || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (batches == 0) return RADHIP_OK;
+    for (uint32_t b = 0; b < batches; ++b) if (counts[b] > T4_S) RH_FAIL(RADHIP_E_INVALID, "a staging buffer holds at most %u keys", T4_S);
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_TRY(rh_ensure_device(idx));
+    unsigned long long *din = nullptr, *dout = nullptr;
+    uint32_t *dc = nullptr;
+    int rc = RADHIP_OK;
+    const size_t bytes = (size_t)batches * 256 * 8;
+    if (hipMalloc((void **)&din, bytes) != hipSuccess || hipMalloc((void **)&dout, bytes) != hipSuccess ||
+        hipMalloc((void **)&dc, (size_t)batches * 4) != hipSuccess) rc = RADHIP_E_NOMEM;
+    if (rc == RADHIP_OK && (hipMemcpy(din, keys, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+                            hipMemcpy(dc, counts, (size_t)batches * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                            hipMemset(dout, 0, bytes) != hipSuccess)) rc = RADHIP_E_HIP;
+    if (rc == RADHIP_OK) {
+        hipLaunchKernelGGL(debug_sort_kernel, dim3(batches), dim3(64), 0, idx->stream, din, dc, dout);
+        if (hipStreamSynchronize(idx->stream) != hipSuccess) rc = RADHIP_E_HIP;
+        else if (hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = RADHIP_E_HIP;
+    }
+    if (din) (void)hipFree(din);
+    if (dout) (void)hipFree(dout);
+    if (dc) (void)hipFree(dc);
+    if (rc != RADHIP_OK) radhip_set_error("radhip_debug_sort_staging failed (%d)", rc);
+    return rc;
+}
+extern "C" uint32_t radhip_debug_staging_capacity(void) { return T4_S; }
 
 extern "C" int radhip_debug_device_keys(radhip_index_t *idx, const uint32_t *a, const uint32_t *o, const uint32_t *slot,
                                         const uint32_t *level, uint64_t n, uint64_t *out_keys) {

@@ -186,6 +186,29 @@ def test_device_keys_match_host_restatement(gpu):
     assert idx.traversal_capacity() >= 256 * 8
 
 
+def test_staging_sort_network(gpu):
+    """trav4_kernel's register-resident 256-slot bitonic network (4 keys per lane, DPP / ds_bpermute exchanges)
+    against numpy on every fill level, with duplicates, extremes and junk behind the valid keys."""
+    from rad_amd import _lib
+    from rad_amd._lib import check, ptr
+    L = _lib.lib()
+    idx = _mk_index(1024, 8)
+    cap = int(L.radhip_debug_staging_capacity())
+    assert 64 <= cap <= 256
+    rng = np.random.default_rng(5)
+    counts = np.array(list(range(1, cap + 1)) + [cap] * 64 + [1, 2, 3, 63, 64, 65, 127, 128, 129], np.uint32)
+    keys = rng.integers(0, 1 << 62, (counts.size, 256), dtype=np.uint64)
+    keys[5::7] >>= np.uint64(40)                                   # many equal high words: the low word decides
+    keys[3::11, ::2] = keys[3::11, 1::2]                           # exact duplicates
+    keys[cap + 1, :8] = np.array([0, 1, (1 << 62) - 1, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFFFFFFFFFE, 0, 1], np.uint64)
+    out = np.empty_like(keys)
+    check(L.radhip_debug_sort_staging(idx._h, ptr(keys), ptr(counts), counts.size, ptr(out)))
+    for b, n in enumerate(counts.tolist()):
+        want = np.sort(keys[b, :n])
+        assert np.array_equal(out[b, :n], want), (b, n)
+        assert (out[b, n:cap] == np.uint64(0xFFFFFFFFFFFFFFFF)).all(), (b, n)
+
+
 @pytest.mark.parametrize("kernel", ["trav4", "trav1"])
 def test_traversal_deep_queue_paths(gpu, oracle, kernel, monkeypatch):
     """n_to_score large enough that the pivot queue flushes hundreds of sorted runs and re-pivots

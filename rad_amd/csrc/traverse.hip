@@ -817,11 +817,11 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
     } else {
         const int forced = trav_forced_kernel();
         t->use4 = trav4_shape_ok(idx) && forced != 1;
-        if (t->use4 && forced != 4) {   // auto: four per wave only beyond two resident rounds of trav_kernel
+        if (t->use4 && forced != 4) {   // auto: four per wave beyond one resident round (and a quarter) of trav_kernel
             uint32_t cap1 = 0;
             int rc1 = trav_capacity_of(idx, false, &cap1);
             if (rc1 != RADHIP_OK) { delete t; return rc1; }
-            t->use4 = nq > 2ull * cap1;
+            t->use4 = (uint64_t)nq * 4ull > 5ull * cap1;
         }
     }
     const uint64_t n_top = idx->n_top;
@@ -1285,11 +1285,12 @@ extern "C" int radhip_debug_device_keys(radhip_index_t *idx, const uint32_t *a, 
 // trav4_kernel packs four traversals into a wavefront (rows <= 16 wide only): the most
 // expansions per HBM request slot when the chip is full.  trav_kernel gives a traversal a whole
 // wavefront and gathers every neighbour's fingerprint speculatively while the probes are in
-// flight: one dependent HBM round trip less per expansion, 2x faster per traversal as long as
-// all of them are resident at once (measured at 100M rows, n_to_score 100k: nq=1 45 vs 80 ms,
-// nq=256 48 vs 123 ms, nq=4096 75 vs 151 ms, nq=8192 152 vs 183 ms, nq=12288 190 vs 194 ms,
-// nq=16384 244 vs 218 ms; trav_kernel holds 6144 resident).  So: four per wave only when the
-// batch is larger than two resident rounds of trav_kernel.
+// flight: one dependent HBM round trip less per expansion, faster per traversal as long as
+// all of them are resident at once (trav_kernel holds 6144).  Measured at the end of round 2 (20M rows,
+// n_to_score 100k, trav_kernel vs trav4_kernel; scripts/crossover.sh): hierarchical corpus nq=1024 146 vs
+// 225 ms, 4096 177 vs 258, 6144 197 vs 272, 8192 280 vs 278, 12288 349 vs 304; round 1's corpus 6144 81 vs
+// 106, 8192 126 vs 113, 12288 156 vs 130.  So: four per wave when the batch exceeds 5/4 of trav_kernel's
+// resident round (round 1's rule was two rounds; trav4_kernel has gained a third since).
 // RADHIP_TRAV=1|4 forces a kernel (tests, profiling); RADHIP_NO_TRAV4 is the older spelling of 1.
 static bool trav4_shape_ok(const radhip_index *idx) { return idx->cap0 <= 16 && idx->M <= 16; }
 

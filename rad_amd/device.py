@@ -294,7 +294,7 @@ class DeviceTraversal:
     @property
     def kernel(self) -> str:
         """The kernel this batch was bound to: four traversals per wavefront for batches larger than
-        two resident rounds of the one-per-wavefront kernel (rows <= 16 wide), else one per wavefront."""
+        5/4 of a resident round of the one-per-wavefront kernel (rows <= 16 wide), else one per wavefront."""
         return "trav4_kernel" if int(self._L.radhip_traversal_kernel(self._h)) == 4 else "trav_kernel"
 
 

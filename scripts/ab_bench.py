@@ -22,7 +22,7 @@ for f in range(0, n, 5_000_000):
 print(f"build {time.time() - t0:.1f}s", flush=True)
 Q = np.ascontiguousarray(X[np.random.default_rng(0).integers(0, n, nq)])
 del X
-os.environ["RADHIP_TRAV"] = "4"; os.environ["RADHIP_TABLE"] = "hash"
+os.environ.setdefault("RADHIP_TRAV", "4"); os.environ["RADHIP_TABLE"] = "hash"
 t = V(); ck(lib.radhip_traversal_create(h, Q.ctypes.data_as(V), C.c_uint32(nq), C.c_uint64(nts), C.c_uint32(0), C.byref(t)))
 for rep in range(4):
     if rep: ck(lib.radhip_traversal_reset(t, Q.ctypes.data_as(V)))

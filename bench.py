@@ -80,7 +80,7 @@ def parse_args():
     ap.add_argument("--sharded-timeout", type=float, default=420.0,
                     help="seconds the sharded leg may take before the line is printed without it (a hung collective must not cost the run)")
     ap.add_argument("--sharded-nq", type=int, default=16384,
-                    help="traversals per rank and step of the sharded leg (a step costs 86 us at 8192, 93 us at 16384: the more the better; 5.5 MB of state each)")
+                    help="traversals per rank and step of the sharded leg (a step costs 86 us at 8192, 89 us at 16384: the more the better; 5.5 MB of state each)")
     ap.add_argument("--exchange", choices=["rccl", "host", "gloo"], default="rccl",
                     help="sharded leg: rccl (product: device buffers, one stream) or host (rehearsal of N ranks on one GPU: "
                          "host-staged buffers over the TCP group; `gloo` is an alias)")

@@ -102,14 +102,40 @@ __device__ __forceinline__ void sh_sc_insert(unsigned long long *sc, uint32_t sl
 #ifndef SH_D
 #define SH_D 8ull
 #endif
+// The ancestors of the new leaf are known before any key is read: up to SH_ANC of them are loaded together (one round
+// trip) and the sift-up runs in registers; deeper heaps (> 8^7 entries at SH_D = 8) finish with the classic loop.
+#define SH_ANC 7
 __device__ __forceinline__ void sh_heap_push(unsigned long long *h, uint64_t &n, unsigned long long key) {
     uint64_t i = n++;
-    while (i > 0) {
-        const uint64_t p = (i - 1) / SH_D;
-        const unsigned long long pk = h[p];
-        if (pk <= key) break;
-        h[i] = pk;
-        i = p;
+    uint64_t ai[SH_ANC];
+    unsigned long long av[SH_ANC];
+    {
+        uint64_t j = i;
+#pragma unroll
+        for (int l = 0; l < SH_ANC; ++l) {
+            const bool has = j > 0;
+            j = has ? (j - 1) / SH_D : 0;
+            ai[l] = has ? j : ~0ull;
+        }
+#pragma unroll
+        for (int l = 0; l < SH_ANC; ++l) av[l] = ai[l] != ~0ull ? h[ai[l]] : 0ull;   // (0 <= every key: stops the sift)
+    }
+    bool up = true;
+#pragma unroll
+    for (int l = 0; l < SH_ANC; ++l) {
+        if (up) {
+            if (ai[l] == ~0ull || av[l] <= key) up = false;
+            else { h[i] = av[l]; i = ai[l]; }
+        }
+    }
+    if (up) {   // more than SH_ANC levels
+        while (i > 0) {
+            const uint64_t p = (i - 1) / SH_D;
+            const unsigned long long pk = h[p];
+            if (pk <= key) break;
+            h[i] = pk;
+            i = p;
+        }
     }
     h[i] = key;
 }
@@ -151,12 +177,47 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
     uint2 *scored = P.scored + (uint64_t)q * P.scored_cap;
     const uint32_t *sin = P.scores_in + (uint64_t)q * P.W;
     // ---- finish: the candidates of the last step are scored now (scored insert, queue insert)
-    for (uint32_t i = 0; i < H.n_pend; ++i) {
-        const uint32_t slot = req[i], v = sin[i];
-        if (H.n_scored >= P.scored_cap || H.heap_n >= P.heap_cap) { H.status = RADHIP_E_CAPACITY; break; }
-        scored[H.n_scored++] = make_uint2(slot, v);
-        sh_sc_insert(sc, P.slog2, slot, v);
-        sh_heap_push(heap, H.heap_n, rh_make_key_dev(rh_q24_dev(v & 0xFFFFu, v >> 16), slot, H.pend_level));
+    if (H.n_pend) {
+        // slots, scores and the first scored-set bucket of every candidate in one round trip (W <= 64; the usual 16
+        // or fewer are unrolled loads in flight together); a preloaded empty bucket is trusted only while no earlier
+        // candidate of this step was stored there
+        const uint64_t smask = (1ull << P.slog2) - 1ull;
+        for (uint32_t base = 0; base < H.n_pend && H.status == 0; base += 16) {
+            uint32_t sl[16], sv[16];
+            uint64_t hb[16], ins[16];
+            unsigned long long eb[16];
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) {
+                const bool on = base + j < H.n_pend;
+                sl[j] = on ? req[base + j] : RADHIP_NO_SLOT;
+                sv[j] = on ? sin[base + j] : 0u;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) {
+                hb[j] = sh_h64((uint64_t)sl[j] + 1ull) & smask;
+                ins[j] = ~0ull;
+                eb[j] = base + j < H.n_pend ? sc[hb[j]] : SH_EMPTY64;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) {
+                if (base + j >= H.n_pend || H.status != 0) continue;
+                if (H.n_scored >= P.scored_cap || H.heap_n >= P.heap_cap) { H.status = RADHIP_E_CAPACITY; continue; }
+                const uint32_t slot = sl[j], v = sv[j];
+                scored[H.n_scored++] = make_uint2(slot, v);
+                uint64_t bi = hb[j];
+                unsigned long long e = eb[j];
+                if (e == SH_EMPTY64) {
+                    bool taken = false;
+#pragma unroll
+                    for (uint32_t t = 0; t < 16; ++t) taken = taken || (t < j && ins[t] == bi);
+                    if (taken) e = sc[bi];
+                }
+                while (e != SH_EMPTY64) { bi = (bi + 1) & smask; e = sc[bi]; }
+                sc[bi] = (unsigned long long)(slot + 1u) | ((unsigned long long)v << 32);
+                ins[j] = bi;
+                sh_heap_push(heap, H.heap_n, rh_make_key_dev(rh_q24_dev(v & 0xFFFFu, v >> 16), slot, H.pend_level));
+            }
+        }
     }
     H.n_pend = 0;
     uint32_t k = 0;

@@ -73,6 +73,11 @@ typedef struct {
     int32_t device;
     int32_t has_vectors;
     int32_t has_graph;
+    /* row-sharded index (one rank's rows of a larger corpus): n above is the size of the WHOLE corpus /
+     * graph, the rows resident on this device are slots [shard_first, shard_first + shard_rows) */
+    int32_t sharded;
+    uint64_t shard_first;
+    uint64_t shard_rows;
 } radhip_index_info_t;
 
 /* replaces usearch Index(ndim=, dtype='b1', metric='tanimoto', connectivity=,
@@ -97,6 +102,16 @@ int radhip_index_synth_vectors(radhip_index_t *idx, uint64_t n, uint64_t first_r
                                uint64_t n_total, uint64_t seed, int mode);
 int radhip_index_read_vectors(const radhip_index_t *idx, uint64_t first, uint64_t count,
                               uint8_t *out_rows);
+/* ONE RANK'S ROWS ONLY (row-sharded multi-GPU mode, BASELINE.json north_star "partition the fingerprint
+ * corpus across the 8 GPUs"): rows = the `count` host rows of slots [first, first+count) of a corpus of
+ * n_total rows / the same range of the closed-form corpus generated on the device.  The index never
+ * allocates, stages or generates the other ranks' rows; it is `sharded` from the start (only the sharded
+ * traversal, radhip_shard_*, reads its fingerprints) and takes the graph over all n_total nodes from
+ * radhip_index_load_graph, radhip_index_synth_graph or radhip_index_broadcast_graph. */
+int radhip_index_load_vectors_shard(radhip_index_t *idx, const uint8_t *rows, uint64_t first, uint64_t count,
+                                    uint64_t n_total);
+int radhip_index_synth_vectors_shard(radhip_index_t *idx, uint64_t count, uint64_t first_row,
+                                     uint64_t n_total, uint64_t seed, int mode);
 
 /* adjacency upload: levels[n] (int8), adj0[n*connectivity_base] and
  * adjU[n_upper_rows*connectivity] padded with RADHIP_NO_SLOT, upper_row[n] =
@@ -205,6 +220,10 @@ int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64_t count, u
 int radhip_search(radhip_index_t *idx, const uint8_t *queries, uint32_t nq, uint32_t k, uint32_t ef,
                   uint32_t *out_slots, uint32_t *out_and, uint32_t *out_or, uint32_t *out_counts,
                   uint64_t *out_evals, uint64_t *out_pops);
+/* the graph half of usearch Index.add for rows that are ALREADY resident (radhip_index_load_vectors /
+ * radhip_index_synth_vectors): links rows [nodes of the graph so far, rows of the corpus) exactly as
+ * radhip_index_add would have, without a host copy of the corpus going through the call */
+int radhip_index_link_resident(radhip_index_t *idx, uint64_t seed, uint32_t max_batch);
 /* level a node inserted at `slot` gets (host arithmetic, integer only) */
 int radhip_level_of(uint64_t seed, uint64_t slot, uint32_t connectivity);
 
@@ -260,7 +279,9 @@ int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t *out);
  * (batches larger than two resident rounds of the one-per-wavefront kernel, rows <= 16 wide), 1 = one per
  * wavefront with speculative fingerprint gathers (small batches, wide rows).  Same results. */
 int radhip_traversal_kernel(const radhip_traversal_t *t);
-/* Which visited/scored table the object uses: 0 = one hash entry per node (the default), 1 = grouped (2 bits
+/* Which visited/scored table the object uses: 2 = bucket table (16-B buckets of four 4-byte entries, ONE request
+ * per probe; the default of the four-per-wavefront kernel), 0 = one 8-byte hash entry per probe (the one-per-
+ * wavefront kernel and the sharded wave engine; RADHIP_TABLE=hash forces it for A/B runs), 1 = grouped (2 bits
  * per node in 16-B chunks of 48 layout ids, 8 chunks to a 128-B line; opt-in with RADHIP_TABLE=group in the
  * environment, needs radhip_index_optimize_layout — fewer HBM lines per expansion, measured slower end to end
  * on the round-2 workloads, see profiles/r02).  Same results. */
@@ -284,13 +305,17 @@ int radhip_traversal_frontier(const radhip_traversal_t *t, uint64_t *out_keys, u
  * the candidates whose rows it owns, and the scores return to the asking rank (reduce-scatter of
  * disjoint contributions).  Strict best-first per traversal: results are bit-identical to the
  * single-GPU traversal of the same corpus and graph for any number of ranks. */
-/* keep rows [first, first+count) of the resident corpus, free the rest (graph, levels, keys stay whole) */
+/* keep rows [first, first+count) of the resident corpus, free the rest (graph, levels, keys stay whole).  For a
+ * rank that did hold everything (the one that built the graph); the others are created with their rows only
+ * (radhip_index_*_shard).  When the device has no room for the shard beside the corpus the shard leaves through
+ * host memory and the corpus is freed first. */
 int radhip_index_keep_rows(radhip_index_t *idx, uint64_t first, uint64_t count);
 typedef struct radhip_shard radhip_shard_t;
 typedef struct radhip_comm radhip_comm_t;
 /* queries_all: world * nq query rows, rank-major — traversal (r, q) belongs to rank r; every rank passes
  * the same array (it scores other ranks' candidates against their queries).  The index must hold rows
  * [row_first, row_first+row_count): the whole corpus, or exactly that range after radhip_index_keep_rows. */
+#define RADHIP_SHARD_OWN_STREAM 2u  /* radhip_shard_create flag: the shard gets a stream of its own (second group of a pair) */
 int radhip_shard_create(radhip_index_t *idx, int rank, int world, uint64_t row_first, uint64_t row_count,
                         const uint8_t *queries_all, uint32_t nq, uint64_t n_to_score, uint32_t flags,
                         radhip_shard_t **out);
@@ -302,10 +327,27 @@ int radhip_shard_reset(radhip_shard_t *s, const uint8_t *queries_all);
  * travel behind the candidates, so all ranks stop at the same step; the host looks at them every fourth
  * step, so up to three empty steps may follow the last useful one) or max_steps (0 = none) */
 int radhip_shard_run(radhip_shard_t *s, radhip_comm_t *comm, uint64_t max_steps, uint64_t *out_steps);
+/* the same loop for TWO groups of traversals at once, each with its own state, stream and communicator (b created
+ * with RADHIP_SHARD_OWN_STREAM, comm_b a second radhip_comm_create): a frontier step is latency-bound end to end,
+ * so one group's step kernel runs while the other group's collectives are in flight.  Results per group are those
+ * of radhip_shard_run.  Both groups stop together (up to a few empty steps for the one that finishes first). */
+int radhip_shard_run_pair(radhip_shard_t *a, radhip_comm_t *comm_a, radhip_shard_t *b, radhip_comm_t *comm_b,
+                          uint64_t max_steps, uint64_t *out_steps);
+/* Failure behaviour of both loops: a traversal that fails ON THE DEVICE (a fixed-capacity structure overflowed)
+ * raises bit 31 of its rank's live word, which travels behind the candidates — every rank sees it at the same step,
+ * leaves the loop and returns RADHIP_E_CAPACITY.  A HOST-side failure of one rank (a HIP / RCCL call) makes that
+ * rank drain its stream, abort its communicator (ncclCommAbort: the peers' collectives fail or their next look
+ * times out after RADHIP_SHARD_TIMEOUT_S, default 300) and return the error; the communicator is unusable afterwards. */
+/* speculation of the thread engine (RADHIP_SHARD_SPEC = 0 | 1 | 2 queue heads expanded speculatively per step, default
+ * 2): scores asked for speculatively, how many of them finished an expansion without another step, how many
+ * expansions that were.  Committed state never depends on it (strict pop order). */
+int radhip_shard_speculation(const radhip_shard_t *s, uint32_t *out_depth, uint64_t *out_requested, uint64_t *out_used,
+                             uint64_t *out_hits);
 /* the same step in host-staged pieces, for an exchange the host program owns (tests; rehearsing N ranks
  * on one GPU): step -> get_requests | exchange | set_requests_all -> evaluate -> get_scores_out |
  * exchange (sum over ranks of block `rank`) | set_scores_in -> step ...   W = radhip_shard_width() slots
- * per traversal and step (RADHIP_NO_SLOT padded); scores are and | or << 16. */
+ * per traversal and step (RADHIP_NO_SLOT padded; the widest adjacency row, times 1 + the speculation depth); scores
+ * are and | or << 16. */
 uint32_t radhip_shard_width(const radhip_shard_t *s);
 /* which step kernel drives the local traversals: 0 = "thread" (one thread per traversal, heap + sets in HBM; the
  * default), 1 = "wave" (the single-GPU traversal kernel cut at the fingerprint read, four traversals per
@@ -335,6 +377,20 @@ int radhip_comm_destroy(radhip_comm_t *c);
 int radhip_comm_allgather_u64(radhip_comm_t *c, const uint64_t *send, uint64_t count, uint64_t *recv);
 int radhip_comm_rank(const radhip_comm_t *c);
 int radhip_comm_world(const radhip_comm_t *c);
+/* what the communicator really spans, from RCCL itself (ncclCommCount / ncclCommUserRank / ncclGetVersion) and
+ * the PCI bus id of the device this rank drives (hipDeviceGetPCIBusId): evidence for the N > 1 bench line */
+typedef struct {
+    int32_t rccl_version;     /* ncclGetVersion code */
+    int32_t comm_count;       /* ncclCommCount */
+    int32_t comm_rank;        /* ncclCommUserRank */
+    int32_t device;           /* HIP device ordinal */
+    char pci_bus_id[32];      /* e.g. "0000:05:00.0" */
+} radhip_comm_info_t;
+int radhip_comm_info(const radhip_comm_t *c, radhip_comm_info_t *out);
+/* the adjacency of `root` (levels, level-0 rows, upper rows, top-level nodes) on every rank: ncclBroadcast of the
+ * device arrays over xGMI, nothing goes through host memory.  The receiving index must have the same
+ * connectivity / connectivity_base; its own graph (if any) is replaced. */
+int radhip_index_broadcast_graph(radhip_index_t *idx, radhip_comm_t *comm, int root);
 
 /* host restatement of the device queue key, exported so CPU tests can check
  * its order against the Redis ZSET order of rad/priority_queue.py:22-42

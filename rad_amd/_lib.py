@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("RADHIP_LIB") or os.path.join(_HERE, "_build", "librad
 
 NO_SLOT = 0xFFFFFFFF
 TRAV_LOG_POPS = 1
+SHARD_OWN_STREAM = 2
 
 E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_STATE, E_CAPACITY, E_RANGE, E_COMM = range(-1, -9, -1)
 
@@ -31,7 +32,13 @@ class IndexInfo(C.Structure):
                 ("connectivity_base", C.c_uint32), ("expansion_add", C.c_uint32),
                 ("max_level", C.c_int32), ("entry", C.c_uint32), ("n_upper_rows", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("device", C.c_int32), ("has_vectors", C.c_int32),
-                ("has_graph", C.c_int32)]
+                ("has_graph", C.c_int32), ("sharded", C.c_int32), ("shard_first", C.c_uint64),
+                ("shard_rows", C.c_uint64)]
+
+
+class CommInfo(C.Structure):
+    _fields_ = [("rccl_version", C.c_int32), ("comm_count", C.c_int32), ("comm_rank", C.c_int32),
+                ("device", C.c_int32), ("pci_bus_id", C.c_char * 32)]
 
 
 class LayoutInfo(C.Structure):
@@ -60,6 +67,13 @@ SIGNATURES = {
     "radhip_index_load_vectors": (C.c_int, [_P, _P, _U64]),
     "radhip_index_synth_vectors": (C.c_int, [_P, _U64, _U64, _U64, _U64, C.c_int]),
     "radhip_index_read_vectors": (C.c_int, [_P, _U64, _U64, _P]),
+    "radhip_index_load_vectors_shard": (C.c_int, [_P, _P, _U64, _U64, _U64]),
+    "radhip_index_synth_vectors_shard": (C.c_int, [_P, _U64, _U64, _U64, _U64, C.c_int]),
+    "radhip_index_link_resident": (C.c_int, [_P, _U64, _U32]),
+    "radhip_index_broadcast_graph": (C.c_int, [_P, _P, C.c_int]),
+    "radhip_comm_info": (C.c_int, [_P, C.POINTER(CommInfo)]),
+    "radhip_shard_run_pair": (C.c_int, [_P, _P, _P, _P, _U64, C.POINTER(_U64)]),
+    "radhip_shard_speculation": (C.c_int, [_P, C.POINTER(_U32), C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64)]),
     "radhip_index_load_graph": (C.c_int, [_P, _U64, _I32, _U32, _P, _P, _P, _P, _U64]),
     "radhip_index_synth_graph": (C.c_int, [_P, _U64]),
     "radhip_index_read_graph": (C.c_int, [_P, _P, _P, _P, _P]),

@@ -540,24 +540,26 @@ __global__ void req_unpack_kernel(const unsigned long long *keys, uint64_t n, ui
     }
 }
 
-extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64_t count, uint64_t seed,
-                                uint32_t max_batch) {
-    if (!idx || (!rows && count)) RH_FAIL(RADHIP_E_INVALID, "null argument");
+// rows == nullptr: the `count` rows behind the graph's last node are resident already (radhip_index_link_resident)
+static int add_impl(radhip_index *idx, const uint8_t *rows, uint64_t count, uint64_t seed, uint32_t max_batch) {
+    const bool resident = rows == nullptr;
     if (count == 0) return RADHIP_OK;
     if (max_batch < 1) max_batch = 1;
     if (max_batch > 65536) max_batch = 65536;
-    std::lock_guard<std::mutex> lk(idx->mu);
     RH_REQUIRE_FULL_CORPUS(idx);
+    RH_REQUIRE_SOUND(idx);
     if (idx->has_graph && idx->g_n && (idx->h_levels.size() != idx->g_n || idx->h_upper_row.size() != idx->g_n)) {
         // graph generated on the device (synthetic): mirror it once; after that add() keeps levels / upper rows
         // itself (the adjacency rows are not needed on the host here)
         RH_TRY(rh_ensure_host_graph(idx));
     }
-    if (idx->has_vectors && idx->has_graph && idx->n != idx->g_n)
-        RH_FAIL(RADHIP_E_STATE, "add() needs corpus and graph of equal size (%llu vs %llu)",
-                (unsigned long long)idx->n, (unsigned long long)idx->g_n);
-    if (idx->has_vectors != idx->has_graph && (idx->n || idx->g_n))
-        RH_FAIL(RADHIP_E_STATE, "add() cannot extend an index that has vectors without a graph (or vice versa)");
+    if (!resident) {
+        if (idx->has_vectors && idx->has_graph && idx->n != idx->g_n)
+            RH_FAIL(RADHIP_E_STATE, "add() needs corpus and graph of equal size (%llu vs %llu)",
+                    (unsigned long long)idx->n, (unsigned long long)idx->g_n);
+        if (idx->has_vectors != idx->has_graph && (idx->n || idx->g_n))
+            RH_FAIL(RADHIP_E_STATE, "add() cannot extend an index that has vectors without a graph (or vice versa)");
+    }
     RH_TRY(rh_ensure_device(idx));
     rh_layout_invalidate(idx);
     const uint64_t first = idx->has_graph ? idx->g_n : 0, total = first + count;
@@ -578,15 +580,18 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
     }
     const uint64_t old_nu = idx->n_upper_rows;
 
-    // Nothing of the index object changes until the last batch is linked: a failure in between (a HIP error, a
-    // device structure that overflowed) leaves the index as it was and extendable (the arrays may keep their
-    // larger allocations, their contents beyond the old size are never read).
-    bool committed = false;
-    auto rollback = [&]() { hl.resize(first); hu.resize(first); };
+    // The index object (sizes, entry point, host mirror) changes only when the last batch is linked.  A failure
+    // before the first reverse-link pass leaves the index as it was and extendable (the arrays may keep their
+    // larger allocations, their contents beyond the old size are never read).  A failure AFTER a reverse-link
+    // pass does not: build_reverse_kernel has written links to the new slots into the rows of existing nodes,
+    // and those slots were never committed — the index is marked poisoned and refuses every further use
+    // (RADHIP_E_STATE) instead of serving edges into rows that do not exist.
+    bool committed = false, reverse_ran = false;
+    auto rollback = [&]() { hl.resize(first); hu.resize(first); if (reverse_ran && first) idx->poisoned = true; };
     // ---- grow device arrays: by half at least, so that many small add() calls stay linear ---------
     {
         const uint64_t need = total, have = idx->d_fp ? idx->fp_cap_rows : 0;
-        if (need > have) {
+        if (!resident && need > have) {
             uint64_t ncap = std::max<uint64_t>(need, have + have / 2);
             uint4 *nfp = nullptr;
             hipError_t e = hipMalloc((void **)&nfp, ncap * idx->row_stride);
@@ -600,10 +605,19 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
             idx->fp_cap_rows = ncap;
             idx->device_bytes += ncap * idx->row_stride;
         }
-        std::vector<uint8_t> stage((size_t)count * idx->row_stride, 0);
-        for (uint64_t i = 0; i < count; ++i)
-            memcpy(stage.data() + i * idx->row_stride, rows + i * idx->row_bytes, idx->row_bytes);
-        if (hipMemcpy((uint8_t *)idx->d_fp + first * idx->row_stride, stage.data(), stage.size(), hipMemcpyHostToDevice) != hipSuccess) { rollback(); RH_FAIL(RADHIP_E_HIP, "upload of the new rows failed"); }
+        // the new rows go up in pieces of 64 MB: the staging copy of a 5M-row add() would otherwise be 640 MB of host memory
+        if (!resident) {
+            const uint64_t piece = std::max<uint64_t>(1, (64ull << 20) / idx->row_stride);
+            std::vector<uint8_t> stage;
+            try { stage.assign((size_t)std::min<uint64_t>(piece, count) * idx->row_stride, 0); }
+            catch (...) { rollback(); RH_FAIL(RADHIP_E_NOMEM, "out of host memory staging the new rows"); }
+            for (uint64_t f = 0; f < count; f += piece) {
+                const uint64_t c = std::min<uint64_t>(piece, count - f);
+                for (uint64_t i = 0; i < c; ++i)
+                    memcpy(stage.data() + i * idx->row_stride, rows + (f + i) * idx->row_bytes, idx->row_bytes);
+                if (hipMemcpy((uint8_t *)idx->d_fp + (first + f) * idx->row_stride, stage.data(), (size_t)c * idx->row_stride, hipMemcpyHostToDevice) != hipSuccess) { rollback(); RH_FAIL(RADHIP_E_HIP, "upload of the new rows failed"); }
+            }
+        }
     }
     {
         int rc = RADHIP_OK;
@@ -755,6 +769,7 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
                     case 8: hipLaunchKernelGGL(build_reverse_kernel<8>, dim3(ng), dim3(64), rlds, idx->stream, RP); break;
                     default: hipLaunchKernelGGL(build_reverse_kernel<16>, dim3(ng), dim3(64), rlds, idx->stream, RP); break;
                 }
+                reverse_ran = true;
                 BH(hipGetLastError());
                 BH(hipStreamSynchronize(idx->stream));
             }
@@ -783,6 +798,23 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
     RH_HIP(hipMalloc((void **)&idx->d_top, std::max<size_t>(idx->n_top, 4) * 4));
     RH_HIP(hipMemcpy(idx->d_top, idx->h_top.data(), (size_t)idx->n_top * 4, hipMemcpyHostToDevice));
     return RADHIP_OK;
+}
+
+extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64_t count, uint64_t seed,
+                                uint32_t max_batch) {
+    if (!idx || (!rows && count)) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    return add_impl(idx, rows, count, seed, max_batch);
+}
+
+extern "C" int radhip_index_link_resident(radhip_index_t *idx, uint64_t seed, uint32_t max_batch) {
+    if (!idx) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (!idx->has_vectors) RH_FAIL(RADHIP_E_STATE, "no vectors loaded");
+    const uint64_t linked = idx->has_graph ? idx->g_n : 0;
+    if (idx->n < linked) RH_FAIL(RADHIP_E_STATE, "the graph has more nodes (%llu) than the corpus has rows (%llu)",
+                                 (unsigned long long)linked, (unsigned long long)idx->n);
+    return add_impl(idx, nullptr, idx->n - linked, seed, max_batch);
 }
 
 extern "C" int radhip_search(radhip_index_t *idx, const uint8_t *queries, uint32_t nq, uint32_t k, uint32_t ef,

@@ -15,3 +15,5 @@ struct radhip_comm {
 // device-buffer collectives on the caller's stream (no host staging, no synchronisation)
 int rh_comm_allgather_dev(radhip_comm *c, const uint32_t *d_send, uint32_t *d_recv, size_t count_u32, hipStream_t st);
 int rh_comm_reduce_scatter_u32_dev(radhip_comm *c, const uint32_t *d_send, uint32_t *d_recv, size_t count_u32, hipStream_t st);
+// ncclCommAbort: the peers' pending collectives fail instead of hanging; the communicator is unusable afterwards
+int rh_comm_abort(radhip_comm *c);

@@ -4,6 +4,7 @@
 // by the host program (bench.py: a plain TCP rendezvous, rad_amd/rendezvous.py; no torch).
 #include "comm.h"
 
+#include <algorithm>
 #include <new>
 
 #define RH_NCCL(expr)                                                                   \
@@ -79,6 +80,7 @@ extern "C" int radhip_comm_allgather_u64(radhip_comm_t *c, const uint64_t *send,
         RH_HIP(hipMalloc(&c->d_recv, rb));
         c->cap_recv = rb;
     }
+    if (!c->comm) RH_FAIL(RADHIP_E_COMM, "the communicator was aborted");
     RH_HIP(hipMemcpyAsync(c->d_send, send, sb, hipMemcpyHostToDevice, c->stream));
     RH_NCCL(ncclAllGather(c->d_send, c->d_recv, count, ncclUint64, c->comm, c->stream));
     RH_HIP(hipMemcpyAsync(recv, c->d_recv, rb, hipMemcpyDeviceToHost, c->stream));
@@ -94,6 +96,7 @@ int rh_comm_allgather_dev(radhip_comm *c, const uint32_t *d_send, uint32_t *d_re
         RH_HIP(hipMemcpyAsync(d_recv, d_send, count_u32 * 4, hipMemcpyDeviceToDevice, st));
         return RADHIP_OK;
     }
+    if (!c->comm) RH_FAIL(RADHIP_E_COMM, "the communicator was aborted");
     RH_NCCL(ncclAllGather(d_send, d_recv, count_u32, ncclUint32, c->comm, st));
     return RADHIP_OK;
 }
@@ -102,9 +105,101 @@ int rh_comm_reduce_scatter_u32_dev(radhip_comm *c, const uint32_t *d_send, uint3
         RH_HIP(hipMemcpyAsync(d_recv, d_send, count_u32 * 4, hipMemcpyDeviceToDevice, st));
         return RADHIP_OK;
     }
+    if (!c->comm) RH_FAIL(RADHIP_E_COMM, "the communicator was aborted");
     RH_NCCL(ncclReduceScatter(d_send, d_recv, count_u32, ncclUint32, ncclSum, c->comm, st));
     return RADHIP_OK;
 }
 
 extern "C" int radhip_comm_rank(const radhip_comm_t *c) { return c ? c->rank : -1; }
 extern "C" int radhip_comm_world(const radhip_comm_t *c) { return c ? c->world : -1; }
+
+extern "C" int radhip_comm_info(const radhip_comm_t *c, radhip_comm_info_t *out) {
+    if (!c || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    memset(out, 0, sizeof *out);
+    int v = 0, cnt = 0, ur = 0;
+    RH_NCCL(ncclGetVersion(&v));
+    if (!c->comm) RH_FAIL(RADHIP_E_COMM, "the communicator was aborted");
+    RH_NCCL(ncclCommCount(c->comm, &cnt));
+    RH_NCCL(ncclCommUserRank(c->comm, &ur));
+    out->rccl_version = v; out->comm_count = cnt; out->comm_rank = ur; out->device = c->device;
+    if (hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof out->pci_bus_id, c->device) != hipSuccess) out->pci_bus_id[0] = 0;
+    return RADHIP_OK;
+}
+
+// abort a communicator whose peers may be blocked in a collective this rank will never enter (an error inside
+// radhip_shard_run): ncclCommAbort makes their pending collectives fail instead of hanging
+int rh_comm_abort(radhip_comm *c) {
+    if (c && c->comm) { (void)ncclCommAbort(c->comm); c->comm = nullptr; }
+    return RADHIP_OK;
+}
+
+// ---- the graph of `root` on every rank, device to device over xGMI ------------------------------------
+void rh_layout_invalidate(radhip_index *idx);
+static int bcast_bytes(radhip_comm *c, void *p, size_t bytes, int root, hipStream_t st) {
+    // pieces of 1 GiB: a level-0 adjacency of 1B nodes is 64 GB
+    const size_t piece = (size_t)1 << 30;
+    for (size_t off = 0; off < bytes; off += piece) {
+        const size_t n = std::min(piece, bytes - off);
+        RH_NCCL(ncclBroadcast((const uint8_t *)p + off, (uint8_t *)p + off, n, ncclUint8, root, c->comm, st));
+    }
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_index_broadcast_graph(radhip_index_t *idx, radhip_comm_t *c, int root) {
+    if (!idx || !c) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (root < 0 || root >= c->world) RH_FAIL(RADHIP_E_INVALID, "root %d out of range", root);
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_TRY(rh_ensure_device(idx));
+    if (idx->device != c->device) RH_FAIL(RADHIP_E_INVALID, "index and communicator live on different devices");
+    const bool is_root = c->rank == root;
+    if (is_root && (!idx->has_graph || !idx->d_graph_valid)) RH_FAIL(RADHIP_E_STATE, "the root has no graph on its device");
+    if (c->world == 1) return RADHIP_OK;
+    if (!c->comm) RH_FAIL(RADHIP_E_COMM, "the communicator was aborted");
+    hipStream_t st = idx->stream;
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (is_root) {
+        h[0] = idx->g_n; h[1] = (unsigned long long)(long long)idx->max_level; h[2] = idx->entry; h[3] = idx->n_upper_rows;
+        h[4] = idx->n_top; h[5] = idx->cap0; h[6] = idx->M; h[7] = 0x52414447ull;
+    }
+    unsigned long long *dh = nullptr;
+    RH_HIP(hipMalloc((void **)&dh, sizeof h));
+    int rc = RADHIP_OK;
+    auto fail = [&](int code) { (void)hipFree(dh); return code; };
+    if (hipMemcpyAsync(dh, h, sizeof h, hipMemcpyHostToDevice, st) != hipSuccess) return fail(RADHIP_E_HIP);
+    if ((rc = bcast_bytes(c, dh, sizeof h, root, st)) != RADHIP_OK) return fail(rc);
+    if (hipMemcpyAsync(h, dh, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(RADHIP_E_HIP);
+    (void)hipFree(dh);
+    if (h[7] != 0x52414447ull) RH_FAIL(RADHIP_E_COMM, "graph broadcast: bad header from rank %d", root);
+    if (h[5] != idx->cap0 || h[6] != idx->M)
+        RH_FAIL(RADHIP_E_INVALID, "graph broadcast: rank %d has rows of %llu / %llu slots, this index %u / %u", root, h[5], h[6], idx->cap0, idx->M);
+    if (!is_root) {
+        rh_layout_invalidate(idx);
+        idx->g_n = h[0]; idx->max_level = (int32_t)(long long)h[1]; idx->entry = (uint32_t)h[2]; idx->n_upper_rows = h[3];
+        if (idx->sharded && idx->n_total != idx->g_n)
+            RH_FAIL(RADHIP_E_INVALID, "graph broadcast: the graph has %llu nodes, this shard belongs to a corpus of %llu rows",
+                    (unsigned long long)idx->g_n, (unsigned long long)idx->n_total);
+        idx->has_graph = false; idx->d_graph_valid = false;
+        RH_TRY(rh_alloc_graph_dev(idx));
+        idx->n_top = (uint32_t)h[4];
+        RH_HIP(hipMalloc((void **)&idx->d_top, std::max<size_t>(idx->n_top, 4) * 4));
+        idx->device_bytes += (size_t)idx->n_top * 4;
+    }
+    RH_TRY(bcast_bytes(c, idx->d_levels, idx->g_n, root, st));
+    RH_TRY(bcast_bytes(c, idx->d_adj0, idx->g_n * idx->cap0 * 4, root, st));
+    RH_TRY(bcast_bytes(c, idx->d_upper_row, idx->g_n * 4, root, st));
+    if (idx->n_upper_rows) RH_TRY(bcast_bytes(c, idx->d_adjU, idx->n_upper_rows * idx->M * 4, root, st));
+    if (idx->n_top) RH_TRY(bcast_bytes(c, idx->d_top, (size_t)idx->n_top * 4, root, st));
+    RH_HIP(hipStreamSynchronize(st));
+    if (!is_root) {
+        idx->h_top.resize(idx->n_top);
+        if (idx->n_top) RH_HIP(hipMemcpy(idx->h_top.data(), idx->d_top, (size_t)idx->n_top * 4, hipMemcpyDeviceToHost));
+        std::vector<int8_t>().swap(idx->h_levels);
+        std::vector<uint32_t>().swap(idx->h_adj0);
+        std::vector<uint32_t>().swap(idx->h_upper_row);
+        std::vector<uint32_t>().swap(idx->h_adjU);
+        idx->h_graph_valid = false;
+        idx->d_graph_valid = true;
+        idx->has_graph = true;
+    }
+    return RADHIP_OK;
+}

@@ -44,7 +44,9 @@ struct radhip_index {
     int device = 0;
     uint64_t n = 0;           // rows resident in d_fp
     bool sharded = false;
-    uint64_t shard_first = 0; // slot of row 0 of d_fp: 0 unless radhip_index_keep_rows dropped the rows of the other ranks
+    uint64_t shard_first = 0; // slot of row 0 of d_fp: 0 unless this index holds one rank's rows only (radhip_index_*_shard, keep_rows)
+    uint64_t n_total = 0;     // sharded: rows of the whole corpus (= nodes of the graph every rank holds); else unused
+    bool poisoned = false;    // a failed add() left reverse links to rows that were never committed: every further use is refused
     // ---- host mirror (adjacency reads need no device: fork-safe) ----------
     uint64_t g_n = 0;         // nodes in the graph
     int32_t max_level = -1;
@@ -99,11 +101,18 @@ int rh_ensure_device(radhip_index *idx);           // lazy HIP init + pending up
 // entry points that address d_fp by slot refuse an index that keeps only its shard of the rows
 #define RH_REQUIRE_FULL_CORPUS(idx)                                                                        \
     do {                                                                                                   \
-        if ((idx)->sharded) RH_FAIL(RADHIP_E_STATE, "this index keeps rows [%llu, %llu) only (radhip_index_keep_rows): " \
+        if ((idx)->sharded) RH_FAIL(RADHIP_E_STATE, "this index holds rows [%llu, %llu) of %llu only (one rank's shard): " \
                                     "use the sharded traversal", (unsigned long long)(idx)->shard_first,   \
-                                    (unsigned long long)((idx)->shard_first + (idx)->n));                  \
+                                    (unsigned long long)((idx)->shard_first + (idx)->n), (unsigned long long)(idx)->n_total); \
+    } while (0)
+#define RH_REQUIRE_SOUND(idx)                                                                              \
+    do {                                                                                                   \
+        if ((idx)->poisoned) RH_FAIL(RADHIP_E_STATE, "a failed add() left this index inconsistent (reverse links to rows " \
+                                     "that were never committed): destroy it and build a new one");        \
     } while (0)
 int rh_ensure_host_graph(radhip_index *idx);       // D2H mirror of a device-generated graph
+int rh_alloc_graph_dev(radhip_index *idx);         // index.hip: (re)allocate the device graph arrays for g_n / n_upper_rows
+int rh_upload_top(radhip_index *idx);              // index.hip: h_top -> d_top
 
 // ------------------------------------------------- device-side primitives --
 #define RH_WAVE 64

@@ -96,6 +96,10 @@ extern "C" int radhip_index_info(const radhip_index_t *idx, radhip_index_info_t 
     memset(o, 0, sizeof *o);
     o->n = idx->has_graph ? idx->g_n : idx->n;
     if (idx->has_vectors && idx->n > o->n) o->n = idx->n;
+    if (idx->sharded && idx->n_total > o->n) o->n = idx->n_total;
+    o->shard_first = idx->sharded ? idx->shard_first : 0;
+    o->shard_rows = idx->has_vectors ? idx->n : 0;
+    o->sharded = idx->sharded ? 1 : 0;
     o->ndim_bits = idx->ndim_bits; o->row_bytes = idx->row_bytes; o->row_stride = idx->row_stride;
     o->connectivity = idx->M; o->connectivity_base = idx->cap0; o->expansion_add = idx->ef_add;
     o->max_level = idx->max_level; o->entry = idx->entry; o->n_upper_rows = idx->n_upper_rows;
@@ -116,7 +120,7 @@ static void dev_free(radhip_index *idx, void *p, size_t bytes) {
     idx->device_bytes -= std::min<uint64_t>(idx->device_bytes, bytes ? bytes : 16);
 }
 
-static int alloc_graph_dev(radhip_index *idx) {
+int rh_alloc_graph_dev(radhip_index *idx) {
     dev_free(idx, idx->d_levels, idx->g_n); idx->d_levels = nullptr;
     // sizes of the previous graph are not tracked separately; a graph is
     // (re)loaded rarely, so the accounting is reset by the caller when needed
@@ -133,7 +137,7 @@ static int alloc_graph_dev(radhip_index *idx) {
     return RADHIP_OK;
 }
 
-static int upload_top(radhip_index *idx) {
+int rh_upload_top(radhip_index *idx) {
     if (idx->d_top) { (void)hipFree(idx->d_top); idx->d_top = nullptr; }
     idx->n_top = (uint32_t)idx->h_top.size();
     RH_TRY(dev_alloc(idx, (void **)&idx->d_top, (size_t)idx->n_top * 4));
@@ -143,6 +147,7 @@ static int upload_top(radhip_index *idx) {
 }
 
 int rh_ensure_device(radhip_index *idx) {
+    RH_REQUIRE_SOUND(idx);
     if (!idx->dev_ready) {
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -168,19 +173,20 @@ int rh_ensure_device(radhip_index *idx) {
     }
     if (idx->has_graph && !idx->d_graph_valid) {
         // graph came from the host (load_graph): upload it
-        RH_TRY(alloc_graph_dev(idx));
+        RH_TRY(rh_alloc_graph_dev(idx));
         RH_HIP(hipMemcpy(idx->d_levels, idx->h_levels.data(), idx->g_n, hipMemcpyHostToDevice));
         RH_HIP(hipMemcpy(idx->d_adj0, idx->h_adj0.data(), idx->g_n * idx->cap0 * 4, hipMemcpyHostToDevice));
         RH_HIP(hipMemcpy(idx->d_upper_row, idx->h_upper_row.data(), idx->g_n * 4, hipMemcpyHostToDevice));
         if (idx->n_upper_rows)
             RH_HIP(hipMemcpy(idx->d_adjU, idx->h_adjU.data(), idx->n_upper_rows * idx->M * 4, hipMemcpyHostToDevice));
-        RH_TRY(upload_top(idx));
+        RH_TRY(rh_upload_top(idx));
         idx->d_graph_valid = true;
     }
     return RADHIP_OK;
 }
 
 int rh_ensure_host_graph(radhip_index *idx) {
+    RH_REQUIRE_SOUND(idx);
     if (!idx->has_graph) RH_FAIL(RADHIP_E_STATE, "no graph loaded");
     if (idx->h_graph_valid) return RADHIP_OK;
     RH_TRY(rh_ensure_device(idx));
@@ -198,26 +204,31 @@ int rh_ensure_host_graph(radhip_index *idx) {
 }
 
 // ------------------------------------------------------------------ corpus
-extern "C" int radhip_index_load_vectors(radhip_index_t *idx, const uint8_t *rows, uint64_t n) {
+static int load_vectors_impl(radhip_index *idx, const uint8_t *rows, uint64_t n, uint64_t first, uint64_t n_total, bool shard) {
     if (!idx || (!rows && n)) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (shard && (n == 0 || first + n > n_total)) RH_FAIL(RADHIP_E_INVALID, "rows [first, first+count) must be a non-empty range of n_total");
     std::lock_guard<std::mutex> lk(idx->mu);
     try {
         idx->h_rows.assign((size_t)n * idx->row_stride, 0);
     } catch (...) {
         RH_FAIL(RADHIP_E_NOMEM, "out of host memory staging %llu rows", (unsigned long long)n);
     }
-    const uint32_t tail_bits = idx->ndim_bits % 8;
-    for (uint64_t i = 0; i < n; ++i) {
-        uint8_t *dst = idx->h_rows.data() + i * idx->row_stride;
-        memcpy(dst, rows + i * idx->row_bytes, idx->row_bytes);
-        (void)tail_bits;  // padding bits beyond ndim are the caller's (np.packbits zero-fills them)
-    }
+    for (uint64_t i = 0; i < n; ++i)   // (padding bits beyond ndim are the caller's: np.packbits zero-fills them)
+        memcpy(idx->h_rows.data() + i * idx->row_stride, rows + i * idx->row_bytes, idx->row_bytes);
     idx->n = n;
-    idx->sharded = false; idx->shard_first = 0;
+    idx->sharded = shard; idx->shard_first = shard ? first : 0; idx->n_total = shard ? n_total : 0;
     idx->h_rows_pending = true;
     idx->has_vectors = true;
     idx->graph_gen++;
     return RADHIP_OK;
+}
+extern "C" int radhip_index_load_vectors(radhip_index_t *idx, const uint8_t *rows, uint64_t n) {
+    return load_vectors_impl(idx, rows, n, 0, n, false);
+}
+// one rank's rows of a corpus of n_total rows: the index never holds (or stages) the rest
+extern "C" int radhip_index_load_vectors_shard(radhip_index_t *idx, const uint8_t *rows, uint64_t first, uint64_t count,
+                                               uint64_t n_total) {
+    return load_vectors_impl(idx, rows, count, first, n_total, true);
 }
 
 // splitmix-style hashing shared (by restatement) with oracle/rad_oracle.c
@@ -308,11 +319,11 @@ __global__ void synth_rows_kernel(uint64_t *fp, uint64_t n, uint32_t words_per_s
     }
 }
 
-extern "C" int radhip_index_synth_vectors(radhip_index_t *idx, uint64_t n, uint64_t first_row,
-                                          uint64_t n_total, uint64_t seed, int mode) {
+static int synth_vectors_impl(radhip_index *idx, uint64_t n, uint64_t first_row, uint64_t n_total, uint64_t seed, int mode, bool shard) {
     if (!idx) RH_FAIL(RADHIP_E_INVALID, "null index");
     if (mode < 0 || mode > 2) RH_FAIL(RADHIP_E_INVALID, "mode must be 0, 1 or 2");
     if (first_row + n > n_total) RH_FAIL(RADHIP_E_INVALID, "rows [first, first+n) exceed n_total");
+    if (shard && n == 0) RH_FAIL(RADHIP_E_INVALID, "a shard holds at least one row");
     std::lock_guard<std::mutex> lk(idx->mu);
     idx->h_rows_pending = false;
     std::vector<uint8_t>().swap(idx->h_rows);
@@ -321,7 +332,7 @@ extern "C" int radhip_index_synth_vectors(radhip_index_t *idx, uint64_t n, uint6
     RH_TRY(dev_alloc(idx, (void **)&idx->d_fp, n * idx->row_stride));
     idx->fp_cap_rows = n;
     idx->n = n;
-    idx->sharded = false; idx->shard_first = 0;
+    idx->sharded = shard; idx->shard_first = shard ? first_row : 0; idx->n_total = shard ? n_total : 0;
     uint32_t wps = idx->row_stride / 8;
     hipLaunchKernelGGL(synth_rows_kernel, dim3(256 * 16), dim3(256), 0, idx->stream, (uint64_t *)idx->d_fp, n,
                        wps, idx->row_bytes, idx->ndim_bits, first_row, n_total, seed, mode);
@@ -330,6 +341,16 @@ extern "C" int radhip_index_synth_vectors(radhip_index_t *idx, uint64_t n, uint6
     idx->has_vectors = true;
     idx->graph_gen++;
     return RADHIP_OK;
+}
+extern "C" int radhip_index_synth_vectors(radhip_index_t *idx, uint64_t n, uint64_t first_row,
+                                          uint64_t n_total, uint64_t seed, int mode) {
+    return synth_vectors_impl(idx, n, first_row, n_total, seed, mode, false);
+}
+// rows [first_row, first_row + count) of the closed-form corpus of n_total rows AS A SHARD: they keep their global
+// slots (row i of the buffer is slot first_row + i), the rest of the corpus never exists on this device
+extern "C" int radhip_index_synth_vectors_shard(radhip_index_t *idx, uint64_t count, uint64_t first_row,
+                                                uint64_t n_total, uint64_t seed, int mode) {
+    return synth_vectors_impl(idx, count, first_row, n_total, seed, mode, true);
 }
 
 // Row-sharded multi-GPU mode: this rank keeps rows [first, first + count) of the corpus it generated /
@@ -343,12 +364,28 @@ extern "C" int radhip_index_keep_rows(radhip_index_t *idx, uint64_t first, uint6
                                                       (unsigned long long)first, (unsigned long long)(first + count),
                                                       (unsigned long long)idx->n);
     RH_TRY(rh_ensure_device(idx));
+    const size_t bytes = count * idx->row_stride;
+    const uint8_t *src = (const uint8_t *)idx->d_fp + first * idx->row_stride;
     uint4 *nfp = nullptr;
-    RH_HIP(hipMalloc((void **)&nfp, count * idx->row_stride));
-    RH_HIP(hipMemcpy(nfp, (const uint8_t *)idx->d_fp + first * idx->row_stride, count * idx->row_stride, hipMemcpyDeviceToDevice));
-    dev_free(idx, idx->d_fp, idx->fp_cap_rows * idx->row_stride);
+    if (hipMalloc((void **)&nfp, bytes) == hipSuccess) {
+        if (hipMemcpy(nfp, src, bytes, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(nfp); RH_FAIL(RADHIP_E_HIP, "device copy of the shard failed"); }
+        dev_free(idx, idx->d_fp, idx->fp_cap_rows * idx->row_stride);
+    } else {
+        // no room for the shard beside the whole corpus: the shard leaves through host memory and the corpus is
+        // freed BEFORE the shard is allocated, so the peak stays at the corpus
+        (void)hipGetLastError();
+        std::vector<uint8_t> stage;
+        try { stage.resize(bytes); } catch (...) { RH_FAIL(RADHIP_E_NOMEM, "out of host memory staging the shard (%zu bytes)", bytes); }
+        RH_HIP(hipMemcpy(stage.data(), src, bytes, hipMemcpyDeviceToHost));
+        dev_free(idx, idx->d_fp, idx->fp_cap_rows * idx->row_stride);
+        idx->d_fp = nullptr; idx->fp_cap_rows = 0; idx->has_vectors = false;
+        RH_HIP(hipMalloc((void **)&nfp, bytes));
+        if (hipMemcpy(nfp, stage.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(nfp); RH_FAIL(RADHIP_E_HIP, "upload of the shard failed"); }
+        idx->has_vectors = true;
+    }
+    idx->n_total = idx->n;
     idx->d_fp = nfp;
-    idx->device_bytes += count * idx->row_stride;
+    idx->device_bytes += bytes;
     idx->fp_cap_rows = count;
     idx->n = count;
     idx->shard_first = first;
@@ -508,16 +545,17 @@ __global__ void synth_graph_kernel(uint64_t n, uint32_t M, uint32_t cap0, int32_
 extern "C" int radhip_index_synth_graph(radhip_index_t *idx, uint64_t seed) {
     if (!idx) RH_FAIL(RADHIP_E_INVALID, "null index");
     if (!idx->has_vectors || idx->n == 0) RH_FAIL(RADHIP_E_STATE, "load or generate vectors first");
-    if (idx->n >= 0xFFFFFFFFull) RH_FAIL(RADHIP_E_INVALID, "n too large");
     std::lock_guard<std::mutex> lk(idx->mu);
+    // a shard generates the graph over the WHOLE corpus (closed form over the slots: no row is read)
+    const uint64_t n = idx->sharded ? idx->n_total : idx->n;
+    if (n >= 0xFFFFFFFFull) RH_FAIL(RADHIP_E_INVALID, "n too large");
     RH_TRY(rh_ensure_device(idx));
     rh_layout_invalidate(idx);
-    const uint64_t n = idx->n;
     const int32_t L = syn_max_level(n, idx->M);
     uint64_t nu = 0;
     for (int l = 1; l <= L; ++l) { uint64_t p = syn_ipow(idx->M, l); nu += (n + p - 1) / p; }
     idx->g_n = n; idx->max_level = L; idx->entry = 0; idx->n_upper_rows = nu;
-    RH_TRY(alloc_graph_dev(idx));
+    RH_TRY(rh_alloc_graph_dev(idx));
     hipLaunchKernelGGL(synth_graph_kernel, dim3(256 * 8), dim3(256), 0, idx->stream, n, idx->M, idx->cap0, L,
                        seed, idx->d_levels, idx->d_adj0, idx->d_upper_row, idx->d_adjU);
     RH_HIP(hipGetLastError());
@@ -526,7 +564,7 @@ extern "C" int radhip_index_synth_graph(radhip_index_t *idx, uint64_t seed) {
     idx->h_top.clear();
     const uint64_t p = syn_ipow(idx->M, L);
     for (uint64_t r = 0; r < n; r += p) idx->h_top.push_back((uint32_t)r);
-    RH_TRY(upload_top(idx));
+    RH_TRY(rh_upload_top(idx));
     idx->h_graph_valid = false;
     std::vector<int8_t>().swap(idx->h_levels);
     std::vector<uint32_t>().swap(idx->h_adj0);
@@ -534,6 +572,7 @@ extern "C" int radhip_index_synth_graph(radhip_index_t *idx, uint64_t seed) {
     std::vector<uint32_t>().swap(idx->h_adjU);
     idx->d_graph_valid = true;
     idx->has_graph = true;
+    idx->graph_gen++;
     return RADHIP_OK;
 }
 

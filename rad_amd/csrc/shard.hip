@@ -37,7 +37,9 @@ void rh_trav_bind_shard(radhip_traversal *t, uint32_t *d_req, const uint32_t *d_
 int rh_trav_enqueue_shard_step(radhip_traversal *t);
 
 #include <algorithm>
+#include <chrono>
 #include <new>
+#include <thread>
 
 #define SH_EMPTY64 0ull
 
@@ -45,11 +47,21 @@ struct ShardHeader {
     uint64_t n_scored, n_pops, n_nbr, heap_n;
     uint32_t prime_at, n_pend, pend_level;
     int32_t status;      // 0 running, 1 n_to_score reached, 2 queue empty, < 0 error
+    uint32_t n_vis;      // entries of the visited set (checked against 3/4 of its size: the probes are unbounded loops)
+    uint32_t n_spec;     // speculative candidates out with the last step (req[W .. W + n_spec))
+    // the speculative expansions of the last step: queue head s was node spec_node[s] on level spec_level[s]; its
+    // unscored neighbours are the spec_cnt[s] candidates from req[W + spec_off[s]] on, in row order
+    uint32_t spec_node[2];
+    uint8_t spec_level[2], spec_cnt[2], spec_off[2], pad_[2];
+    uint64_t spec_req, spec_hit, spec_used;   // statistics: speculative scores asked for / expansions finished from them / scores used
 };
 
 struct ShardParams {
     const uint32_t *adj0, *upper_row, *adjU, *top;
-    uint32_t n_top, cap0, capU, nq, W;
+    uint32_t n_top, cap0, capU, nq;
+    uint32_t W;                  // widest adjacency row = candidates one expansion can need
+    uint32_t Wt;                 // request slots per traversal and step: W needed + spec * W speculative
+    uint32_t spec;               // queue heads expanded speculatively per step (0, 1 or 2)
     int32_t start_level;
     uint64_t n_to_score;
     ShardHeader *hdr;
@@ -57,11 +69,14 @@ struct ShardParams {
     unsigned long long *vis; uint32_t vlog2;      // ((slot << 4) | level) + 1
     unsigned long long *sc; uint32_t slog2;       // (slot + 1) | packed counts << 32
     uint2 *scored; uint64_t scored_cap;
-    uint32_t *req;               // [nq * W + 16]: candidate slots of this step, then the live count
-    const uint32_t *scores_in;   // [nq * W]: and | or << 16 of the previous step's candidates
+    uint32_t *req;               // [nq * Wt + 16]: candidate slots of this step, then the live count
+    const uint32_t *scores_in;   // [nq * Wt]: and | or << 16 of the previous step's candidates
     uint32_t *poplog_nodes; uint8_t *poplog_levels; uint64_t poplog_cap;
     uint32_t max_inner;          // pops per step at most while nothing needs a score
 };
+// the live word behind a rank's candidates: live traversals in bits 0..30, bit 31 = a traversal of this rank
+// failed on the device (every rank sees it in the all-gather and the loop ends everywhere at the same step)
+#define SH_POISON 0x80000000u
 
 __device__ __forceinline__ uint64_t sh_h64(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
@@ -69,33 +84,17 @@ __device__ __forceinline__ uint64_t sh_h64(uint64_t x) {
     x ^= x >> 33;
     return x;
 }
-// true if the key was already present, else inserts it
-__device__ __forceinline__ bool sh_vis_tas(unsigned long long *vis, uint32_t vlog2, uint32_t slot, uint32_t level) {
+// true if the key was already present, else inserts it (n_ins counts the inserts: the caller bounds the fill)
+__device__ __forceinline__ bool sh_vis_tas(unsigned long long *vis, uint32_t vlog2, uint32_t slot, uint32_t level, uint32_t &n_ins) {
     const unsigned long long k1 = (((unsigned long long)slot << 4) | level) + 1ull;
     const uint64_t mask = (1ull << vlog2) - 1ull;
     uint64_t i = sh_h64(k1) & mask;
     for (;;) {
         const unsigned long long e = vis[i];
-        if (e == SH_EMPTY64) { vis[i] = k1; return false; }
+        if (e == SH_EMPTY64) { vis[i] = k1; n_ins++; return false; }
         if (e == k1) return true;
         i = (i + 1) & mask;
     }
-}
-__device__ __forceinline__ bool sh_sc_find(const unsigned long long *sc, uint32_t slog2, uint32_t slot, uint32_t *val) {
-    const uint64_t mask = (1ull << slog2) - 1ull;
-    uint64_t i = sh_h64((uint64_t)slot + 1ull) & mask;
-    for (;;) {
-        const unsigned long long e = sc[i];
-        if (e == SH_EMPTY64) return false;
-        if ((uint32_t)e == slot + 1u) { *val = (uint32_t)(e >> 32); return true; }
-        i = (i + 1) & mask;
-    }
-}
-__device__ __forceinline__ void sh_sc_insert(unsigned long long *sc, uint32_t slog2, uint32_t slot, uint32_t val) {
-    const uint64_t mask = (1ull << slog2) - 1ull;
-    uint64_t i = sh_h64((uint64_t)slot + 1ull) & mask;
-    while (sc[i] != SH_EMPTY64) i = (i + 1) & mask;
-    sc[i] = (unsigned long long)(slot + 1u) | ((unsigned long long)val << 32);
 }
 // 8-ary min-heap of u64 keys: a level is one 64-B line, so a pop costs ~log8(n) dependent line reads instead
 // of 2 log2(n) (the step kernel is one thread per traversal: dependent reads are what a step costs)
@@ -162,78 +161,98 @@ __device__ __forceinline__ unsigned long long sh_heap_pop(unsigned long long *h,
     return top;
 }
 
+// One frontier step of one traversal per thread.  Speculation (P.spec > 0): a score is a pure function of (query,
+// row), so besides the candidates the traversal NEEDS (the unscored neighbours of the expansion it stopped at) a
+// step also asks for the unscored neighbours of the next P.spec queue heads.  Nothing of that is committed: the
+// scored list, the queue and the visited set only change in strict pop order, exactly as without speculation
+// (rad/coordination_service.py:369-395).  When the next pop IS the head that was expanded speculatively (3 times
+// out of 4: the scores that just arrived rarely beat it) and every unscored neighbour it has now is among the
+// speculative candidates, the expansion finishes at once from their scores instead of costing another step.
 __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= P.nq) return;
     ShardHeader H = P.hdr[q];
-    uint32_t *req = P.req + (uint64_t)q * P.W;
+    uint32_t *req = P.req + (uint64_t)q * P.Wt;
+    uint32_t *live = P.req + (uint64_t)P.nq * P.Wt;
     if (H.status != 0) {
-        if (H.n_pend) { for (uint32_t i = 0; i < P.W; ++i) req[i] = RADHIP_NO_SLOT; H.n_pend = 0; P.hdr[q] = H; }
+        if (H.n_pend || H.n_spec) { for (uint32_t i = 0; i < P.Wt; ++i) req[i] = RADHIP_NO_SLOT; H.n_pend = 0; H.n_spec = 0; P.hdr[q] = H; }
+        if (H.status < 0) atomicOr(live, SH_POISON);
         return;
     }
     unsigned long long *heap = P.heap + (uint64_t)q * P.heap_cap;
     unsigned long long *vis = P.vis + ((uint64_t)q << P.vlog2);
     unsigned long long *sc = P.sc + ((uint64_t)q << P.slog2);
     uint2 *scored = P.scored + (uint64_t)q * P.scored_cap;
-    const uint32_t *sin = P.scores_in + (uint64_t)q * P.W;
-    // ---- finish: the candidates of the last step are scored now (scored insert, queue insert)
+    const uint32_t *sin = P.scores_in + (uint64_t)q * P.Wt;
+    const uint64_t vmask = (1ull << P.vlog2) - 1ull, smask = (1ull << P.slog2) - 1ull;
+    const uint32_t vis_limit = (uint32_t)(((1ull << P.vlog2) / 4ull) * 3ull);
+
+    // ---- commit up to 16 scored candidates in order: scored list, scored set, queue (rad/coordination_service.py:
+    // 377-389).  The first scored-set bucket of every candidate is loaded together (one round trip); a preloaded
+    // empty bucket is trusted only while no earlier candidate of the block was stored there.
+    auto commit16 = [&](const uint32_t (&sl)[16], const uint32_t (&sv)[16], uint32_t n, uint32_t level) {
+        uint64_t hb[16], ins[16];
+        unsigned long long eb[16];
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            hb[j] = sh_h64((uint64_t)sl[j] + 1ull) & smask;
+            ins[j] = ~0ull;
+            eb[j] = j < n ? sc[hb[j]] : SH_EMPTY64;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            if (j >= n || H.status != 0) continue;
+            if (H.n_scored >= P.scored_cap || H.heap_n >= P.heap_cap) { H.status = RADHIP_E_CAPACITY; continue; }
+            const uint32_t slot = sl[j], v = sv[j];
+            scored[H.n_scored++] = make_uint2(slot, v);
+            uint64_t bi = hb[j];
+            unsigned long long e = eb[j];
+            if (e == SH_EMPTY64) {
+                bool taken = false;
+#pragma unroll
+                for (uint32_t t = 0; t < 16; ++t) taken = taken || (t < j && ins[t] == bi);
+                if (taken) e = sc[bi];
+            }
+            while (e != SH_EMPTY64) { bi = (bi + 1) & smask; e = sc[bi]; }
+            sc[bi] = (unsigned long long)(slot + 1u) | ((unsigned long long)v << 32);
+            ins[j] = bi;
+            sh_heap_push(heap, H.heap_n, rh_make_key_dev(rh_q24_dev(v & 0xFFFFu, v >> 16), slot, level));
+        }
+    };
+
+    // ---- finish: the candidates of the last step are scored now
     if (H.n_pend) {
-        // slots, scores and the first scored-set bucket of every candidate in one round trip (W <= 64; the usual 16
-        // or fewer are unrolled loads in flight together); a preloaded empty bucket is trusted only while no earlier
-        // candidate of this step was stored there
-        const uint64_t smask = (1ull << P.slog2) - 1ull;
         for (uint32_t base = 0; base < H.n_pend && H.status == 0; base += 16) {
             uint32_t sl[16], sv[16];
-            uint64_t hb[16], ins[16];
-            unsigned long long eb[16];
 #pragma unroll
             for (uint32_t j = 0; j < 16; ++j) {
                 const bool on = base + j < H.n_pend;
                 sl[j] = on ? req[base + j] : RADHIP_NO_SLOT;
                 sv[j] = on ? sin[base + j] : 0u;
             }
-#pragma unroll
-            for (uint32_t j = 0; j < 16; ++j) {
-                hb[j] = sh_h64((uint64_t)sl[j] + 1ull) & smask;
-                ins[j] = ~0ull;
-                eb[j] = base + j < H.n_pend ? sc[hb[j]] : SH_EMPTY64;
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < 16; ++j) {
-                if (base + j >= H.n_pend || H.status != 0) continue;
-                if (H.n_scored >= P.scored_cap || H.heap_n >= P.heap_cap) { H.status = RADHIP_E_CAPACITY; continue; }
-                const uint32_t slot = sl[j], v = sv[j];
-                scored[H.n_scored++] = make_uint2(slot, v);
-                uint64_t bi = hb[j];
-                unsigned long long e = eb[j];
-                if (e == SH_EMPTY64) {
-                    bool taken = false;
-#pragma unroll
-                    for (uint32_t t = 0; t < 16; ++t) taken = taken || (t < j && ins[t] == bi);
-                    if (taken) e = sc[bi];
-                }
-                while (e != SH_EMPTY64) { bi = (bi + 1) & smask; e = sc[bi]; }
-                sc[bi] = (unsigned long long)(slot + 1u) | ((unsigned long long)v << 32);
-                ins[j] = bi;
-                sh_heap_push(heap, H.heap_n, rh_make_key_dev(rh_q24_dev(v & 0xFFFFu, v >> 16), slot, H.pend_level));
-            }
+            commit16(sl, sv, H.n_pend - base < 16u ? H.n_pend - base : 16u, H.pend_level);
         }
     }
     H.n_pend = 0;
+    const uint32_t n_cache = H.n_spec;     // speculative scores of the last step: valid for this step only
     uint32_t k = 0;
+    bool primed_now = false;
     if (H.status == 0 && H.prime_at < P.n_top) {
-        // ---- prime (rad/traverser.py:141-170): W top-level nodes per step; distinct, nothing scored yet
-        while (H.prime_at < P.n_top && k < P.W) {
+        // ---- prime (rad/traverser.py:141-170): Wt top-level nodes per step; distinct, nothing scored yet
+        while (H.prime_at < P.n_top && k < P.Wt) {
             const uint32_t slot = P.top[H.prime_at++];
-            (void)sh_vis_tas(vis, P.vlog2, slot, (uint32_t)P.start_level);
+            (void)sh_vis_tas(vis, P.vlog2, slot, (uint32_t)P.start_level, H.n_vis);
             req[k++] = slot;
         }
         H.pend_level = (uint32_t)P.start_level;
+        primed_now = true;
     } else if (H.status == 0) {
-        // ---- pop / expand until a neighbour needs a score (or max_inner pops without one)
-        for (uint32_t it = 0; it < P.max_inner; ++it) {
+        // ---- pop / expand until a neighbour needs a score it does not have (or max_inner pops without one)
+        uint32_t hits = 0;
+        for (uint32_t it = 0; it < P.max_inner + hits; ++it) {
             if (H.n_scored >= P.n_to_score) { H.status = 1; break; }
             if (H.heap_n == 0) { H.status = 2; break; }
+            if (H.n_vis > vis_limit) { H.status = RADHIP_E_CAPACITY; break; }
             const unsigned long long key = sh_heap_pop(heap, H.heap_n);
             uint32_t slot, level;
             rh_decode_key(key, &slot, &level);
@@ -249,7 +268,6 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
             // loads, one round trip) before the entries are resolved in row order — a thread's dependent reads are
             // what a step costs.  A preloaded EMPTY visited bucket is only trusted if no earlier neighbour of this row
             // was inserted there; the scored set does not change inside this loop.
-            const uint64_t vmask = (1ull << P.vlog2) - 1ull, smask = (1ull << P.slog2) - 1ull;
             bool row_end = false;
             for (uint32_t base = 0; base < cap && !row_end && H.status == 0; base += 16) {
                 uint32_t nbv[16];
@@ -287,7 +305,7 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
                     }
                     bool seen = false;
                     for (;;) {
-                        if (e == SH_EMPTY64) { vis[i] = k1; ins[j] = i; break; }
+                        if (e == SH_EMPTY64) { vis[i] = k1; ins[j] = i; H.n_vis++; break; }
                         if (e == k1) { seen = true; break; }
                         i = (i + 1) & vmask;
                         e = vis[i];
@@ -309,10 +327,38 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
                     } else req[k++] = nb;
                 }
             }
+            // ---- every unscored neighbour among the speculative candidates of the last step?  Then their scores are
+            // here already: commit them now, in row order, and go on popping.  (The new nodes of this expansion are a
+            // subsequence of what the speculative expansion of the same (node, level) found: nothing gets unscored.)
+            if (k && H.status == 0 && n_cache && k <= 16u) {
+                int seg = -1;
+                if (H.spec_cnt[0] && H.spec_node[0] == slot && H.spec_level[0] == level) seg = 0;
+                else if (H.spec_cnt[1] && H.spec_node[1] == slot && H.spec_level[1] == level) seg = 1;
+                if (seg >= 0) {
+                    const uint32_t off = P.W + H.spec_off[seg], cn = H.spec_cnt[seg];
+                    uint32_t sl[16], sv[16];
+                    uint32_t j = 0, got = 0;
+                    for (uint32_t i = 0; i < 16u; ++i) { sl[i] = RADHIP_NO_SLOT; sv[i] = 0u; }
+                    for (uint32_t i = 0; i < 16u; ++i) {
+                        if (i >= k) break;
+                        const uint32_t want = req[i];
+                        while (j < cn && req[off + j] != want) ++j;
+                        if (j >= cn) break;
+                        sl[i] = want; sv[i] = sin[off + j];
+                        ++j; ++got;
+                    }
+                    if (got == k) {
+                        commit16(sl, sv, k, level);
+                        H.spec_hit++; H.spec_used += k;
+                        k = 0;
+                        if (hits < P.spec) hits++;
+                    }
+                }
+            }
             H.pend_level = level;
             if (H.status == 0 && level > 0) {
                 const uint32_t nl = level - 1u;
-                if (!sh_vis_tas(vis, P.vlog2, slot, nl)) {
+                if (!sh_vis_tas(vis, P.vlog2, slot, nl, H.n_vis)) {
                     if (H.heap_n >= P.heap_cap) H.status = RADHIP_E_CAPACITY;
                     else sh_heap_push(heap, H.heap_n, rh_make_key_dev((uint32_t)(key >> 38), slot, nl));
                 }
@@ -320,10 +366,74 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
             if (k || H.status != 0) break;
         }
     }
-    for (uint32_t i = k; i < P.W; ++i) req[i] = RADHIP_NO_SLOT;
+    for (uint32_t i = k; i < P.W && i < P.Wt; ++i) req[i] = RADHIP_NO_SLOT;
     H.n_pend = k;
+    // ---- speculate: the unscored neighbours of the next queue heads (the head itself, then the smaller of its
+    // children in the 8-ary heap: the runner-up is one of them).  Read-only: no visited mark, nothing inserted.
+    uint32_t ns = 0;
+    H.spec_cnt[0] = H.spec_cnt[1] = 0;
+    if (P.spec && H.status == 0 && !primed_now && H.prime_at >= P.n_top && H.heap_n > 0) {
+        for (uint32_t s = 0; s < P.spec && s < 2u; ++s) {
+            unsigned long long hk = RH_KEY_INF;
+            if (s == 0) hk = heap[0];
+            else {
+                const uint64_t c1 = H.heap_n < 1 + SH_D ? H.heap_n : 1 + SH_D;
+                unsigned long long ck[SH_D];
+#pragma unroll
+                for (uint64_t j = 0; j < SH_D; ++j) ck[j] = 1 + j < c1 ? heap[1 + j] : RH_KEY_INF;
+#pragma unroll
+                for (uint64_t j = 0; j < SH_D; ++j) hk = ck[j] < hk ? ck[j] : hk;
+            }
+            if (hk == RH_KEY_INF) break;
+            uint32_t slot, level;
+            rh_decode_key(hk, &slot, &level);
+            const uint32_t cap = level == 0 ? P.cap0 : P.capU;
+            const uint32_t *row = level == 0 ? P.adj0 + (uint64_t)slot * P.cap0
+                                             : P.adjU + ((uint64_t)P.upper_row[slot] + (level - 1u)) * P.capU;
+            const uint32_t off0 = ns;
+            bool row_end = false;
+            for (uint32_t base = 0; base < cap && !row_end; base += 16) {
+                uint32_t nbv[16];
+                unsigned long long es[16];
+                uint64_t hs[16];
+                uint32_t cnt16 = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 16; ++j) {
+                    nbv[j] = (base + j < cap && !row_end) ? row[base + j] : RADHIP_NO_SLOT;
+                    if (nbv[j] == RADHIP_NO_SLOT) row_end = true; else cnt16 = j + 1;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 16; ++j) {
+                    es[j] = 0ull; hs[j] = 0;
+                    if (j < cnt16) { hs[j] = sh_h64((uint64_t)nbv[j] + 1ull) & smask; es[j] = sc[hs[j]]; }
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 16; ++j) {
+                    if (j >= cnt16) continue;
+                    const uint32_t nb = nbv[j];
+                    uint64_t si = hs[j];
+                    unsigned long long se = es[j];
+                    bool found = false;
+                    for (;;) {
+                        if (se == SH_EMPTY64) break;
+                        if ((uint32_t)se == nb + 1u) { found = true; break; }
+                        si = (si + 1) & smask;
+                        se = sc[si];
+                    }
+                    if (!found && P.W + ns < P.Wt) req[P.W + ns++] = nb;
+                }
+            }
+            H.spec_node[s] = slot; H.spec_level[s] = (uint8_t)level; H.spec_off[s] = (uint8_t)off0;
+            H.spec_cnt[s] = (uint8_t)(ns - off0 > 255u ? 255u : ns - off0);
+        }
+        H.spec_req += ns;
+    }
+    if (!primed_now) for (uint32_t i = P.W + ns; i < P.Wt; ++i) req[i] = RADHIP_NO_SLOT;
+    else for (uint32_t i = (k > P.W ? k : P.W); i < P.Wt; ++i) req[i] = RADHIP_NO_SLOT;
+    H.n_spec = ns;
     P.hdr[q] = H;
-    if (H.status == 0) atomicAdd(&P.req[(uint64_t)P.nq * P.W], 1u);   // live traversals of this rank
+    if (H.status == 0) atomicAdd(live, 1u);   // live traversals of this rank
+    else if (H.status < 0) atomicOr(live, SH_POISON);
 }
 
 // ---- candidates of every rank x the rows this rank owns: LPR lanes per candidate, U in flight per lane
@@ -384,7 +494,10 @@ __global__ __launch_bounds__(256) void shard_eval_kernel(EvalParams P) {
 struct radhip_shard {
     radhip_index *idx = nullptr;
     int rank = 0, world = 1;
-    uint32_t nq = 0, W = 0;
+    uint32_t nq = 0, W = 0;       // W = request slots per traversal and step (row width x (1 + spec))
+    uint32_t Wrow = 0, spec = 0;
+    hipStream_t stream = nullptr; // the stream this shard's kernels and collectives run on (the index's, or its own: pairs)
+    bool own_stream = false;
     uint64_t n_to_score = 0, first = 0, count = 0;
     ShardParams P{};
     EvalParams E{};
@@ -409,6 +522,7 @@ extern "C" int radhip_shard_destroy(radhip_shard_t *s) {
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return RADHIP_OK;
 }
@@ -445,21 +559,33 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     radhip_shard *s = new (std::nothrow) radhip_shard();
     if (!s) { lk.unlock(); if (wave) (void)radhip_traversal_destroy(wave); RH_FAIL(RADHIP_E_NOMEM, "out of host memory"); }
     s->wave = wave;
+    s->stream = idx->stream;
+    if ((flags & RADHIP_SHARD_OWN_STREAM) && !wave) {
+        if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; lk.unlock(); RH_FAIL(RADHIP_E_HIP, "hipStreamCreate failed"); }
+        s->own_stream = true;
+    }
     s->idx = idx; s->rank = rank; s->world = world; s->nq = nq; s->n_to_score = std::min<uint64_t>(n_to_score, idx->g_n);
     s->first = row_first; s->count = row_count; s->graph_gen = idx->graph_gen;
-    const uint32_t W = std::max<uint32_t>(idx->cap0, idx->M);
-    s->W = W;
+    // request slots per traversal and step: the widest adjacency row (what one expansion can need) plus as much again
+    // for every queue head that is expanded speculatively (RADHIP_SHARD_SPEC = 0, 1 or 2; thread engine only)
+    const uint32_t Wrow = std::max<uint32_t>(idx->cap0, idx->M);
+    uint32_t spec = wave ? 0u : 2u;
+    if (const char *e = getenv("RADHIP_SHARD_SPEC")) { const int v = atoi(e); if (v >= 0 && v <= 2 && !wave) spec = (uint32_t)v; }
+    const uint32_t W = Wrow * (1u + spec);
+    s->W = W; s->Wrow = Wrow; s->spec = spec;
     const uint64_t n_top = idx->n_top;
     const uint64_t scored_cap = s->n_to_score + W + n_top;
     const uint64_t up_pairs = idx->n_upper_rows + n_top * (uint64_t)(idx->max_level + 1);
     // queue entries = scored nodes (one level-0 entry each) + visits above level 0: the traversal kernels' estimate
     // (scored_cap * 8 / connectivity) with a factor of two on top, never more than the graph has
-    const uint64_t heap_cap = scored_cap + std::min<uint64_t>(up_pairs, scored_cap * 16 / idx->M + 4096) + 64;
+    uint64_t heap_cap = scored_cap + std::min<uint64_t>(up_pairs, scored_cap * 16 / idx->M + 4096) + 64;
+    // (test hook: a queue that is too small, so that a traversal fails on the device in the middle of a run)
+    if (const char *e = getenv("RADHIP_SHARD_TEST_HEAP_CAP")) { const long long v = atoll(e); if (v > 0) heap_cap = (uint64_t)v; }
     const uint32_t vlog2 = std::max<uint32_t>(8, sh_log2_ceil(heap_cap + heap_cap / 2));
     const uint32_t slog2 = std::max<uint32_t>(8, sh_log2_ceil(2 * scored_cap));
     ShardParams &P = s->P;
     P.adj0 = idx->d_adj0; P.upper_row = idx->d_upper_row; P.adjU = idx->d_adjU; P.top = idx->d_top;
-    P.n_top = idx->n_top; P.cap0 = idx->cap0; P.capU = idx->M; P.nq = nq; P.W = W;
+    P.n_top = idx->n_top; P.cap0 = idx->cap0; P.capU = idx->M; P.nq = nq; P.W = Wrow; P.Wt = W; P.spec = spec;
     P.start_level = idx->max_level > 0 ? idx->max_level - 1 : 0;
     P.n_to_score = s->n_to_score; P.heap_cap = heap_cap; P.vlog2 = vlog2; P.slog2 = slog2; P.scored_cap = scored_cap;
     // pops per step while nothing needs a score: the step ends with its slowest traversal, so a long inner loop
@@ -545,7 +671,7 @@ extern "C" int radhip_shard_reset(radhip_shard_t *s, const uint8_t *queries_all)
         for (uint32_t b = 0; b < idx->row_bytes; ++b) p += (uint32_t)__builtin_popcount(queries_all[i * idx->row_bytes + b]);
         pop[i] = p;
     }
-    hipStream_t st = idx->stream;
+    hipStream_t st = s->stream;
     RH_HIP(hipMemcpyAsync(s->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, st));
     RH_HIP(hipMemcpyAsync(s->d_qpop, pop.data(), tq * 4, hipMemcpyHostToDevice, st));
     if (!s->wave) {
@@ -561,6 +687,23 @@ extern "C" int radhip_shard_reset(radhip_shard_t *s, const uint8_t *queries_all)
 }
 
 extern "C" uint32_t radhip_shard_width(const radhip_shard_t *s) { return s ? s->W : 0; }
+extern "C" int radhip_shard_speculation(const radhip_shard_t *s, uint32_t *out_depth, uint64_t *out_requested, uint64_t *out_used,
+                                        uint64_t *out_hits) {
+    if (!s) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (out_depth) *out_depth = s->spec;
+    uint64_t rq = 0, us = 0, hi = 0;
+    if (!s->wave && s->spec) {
+        std::lock_guard<std::mutex> lk(s->idx->mu);
+        RH_HIP(hipSetDevice(s->idx->device));
+        std::vector<ShardHeader> hdr(s->nq);
+        RH_HIP(hipMemcpy(hdr.data(), s->P.hdr, (size_t)s->nq * sizeof(ShardHeader), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < s->nq; ++i) { rq += hdr[i].spec_req; us += hdr[i].spec_used; hi += hdr[i].spec_hit; }
+    }
+    if (out_requested) *out_requested = rq;
+    if (out_used) *out_used = us;
+    if (out_hits) *out_hits = hi;
+    return RADHIP_OK;
+}
 extern "C" int radhip_shard_engine(const radhip_shard_t *s) { return s && s->wave ? 1 : 0; }
 extern "C" uint64_t radhip_shard_state_bytes(const radhip_shard_t *s) { return s ? s->state_bytes : 0; }
 
@@ -571,12 +714,12 @@ static int shard_check(radhip_shard *s) {
     return RADHIP_OK;
 }
 
-// enqueue one step kernel on the index's stream (no synchronisation)
+// enqueue one step kernel on the shard's stream (no synchronisation)
 static int shard_enqueue_step(radhip_shard *s, bool zero_live) {
     // (in the product loop the evaluation kernel of the step before has zeroed the live count: one launch less)
-    if (zero_live) RH_HIP(hipMemsetAsync(s->d_req + (size_t)s->nq * s->W, 0, 64, s->idx->stream));
+    if (zero_live) RH_HIP(hipMemsetAsync(s->d_req + (size_t)s->nq * s->W, 0, 64, s->stream));
     if (s->wave) return rh_trav_enqueue_shard_step(s->wave);
-    hipLaunchKernelGGL(shard_step_kernel, dim3((s->nq + 63u) / 64u), dim3(64), 0, s->idx->stream, s->P);
+    hipLaunchKernelGGL(shard_step_kernel, dim3((s->nq + 63u) / 64u), dim3(64), 0, s->stream, s->P);
     RH_HIP(hipGetLastError());
     return RADHIP_OK;
 }
@@ -587,11 +730,11 @@ static int shard_enqueue_eval(radhip_shard *s) {
     const uint64_t per_block = 4ull * (64 / s->idx->lpr) * 4ull;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((total + per_block - 1) / per_block, (uint64_t)n_cu * 8));
     switch (s->idx->lpr) {
-        case 1: hipLaunchKernelGGL(shard_eval_kernel<1>, dim3(grid), dim3(256), 0, s->idx->stream, s->E); break;
-        case 2: hipLaunchKernelGGL(shard_eval_kernel<2>, dim3(grid), dim3(256), 0, s->idx->stream, s->E); break;
-        case 4: hipLaunchKernelGGL(shard_eval_kernel<4>, dim3(grid), dim3(256), 0, s->idx->stream, s->E); break;
-        case 8: hipLaunchKernelGGL(shard_eval_kernel<8>, dim3(grid), dim3(256), 0, s->idx->stream, s->E); break;
-        default: hipLaunchKernelGGL(shard_eval_kernel<16>, dim3(grid), dim3(256), 0, s->idx->stream, s->E); break;
+        case 1: hipLaunchKernelGGL(shard_eval_kernel<1>, dim3(grid), dim3(256), 0, s->stream, s->E); break;
+        case 2: hipLaunchKernelGGL(shard_eval_kernel<2>, dim3(grid), dim3(256), 0, s->stream, s->E); break;
+        case 4: hipLaunchKernelGGL(shard_eval_kernel<4>, dim3(grid), dim3(256), 0, s->stream, s->E); break;
+        case 8: hipLaunchKernelGGL(shard_eval_kernel<8>, dim3(grid), dim3(256), 0, s->stream, s->E); break;
+        default: hipLaunchKernelGGL(shard_eval_kernel<16>, dim3(grid), dim3(256), 0, s->stream, s->E); break;
     }
     RH_HIP(hipGetLastError());
     return RADHIP_OK;
@@ -602,16 +745,17 @@ extern "C" int radhip_shard_step(radhip_shard_t *s, uint32_t *out_live) {
     if (!s) RH_FAIL(RADHIP_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_TRY(shard_check(s));
-    RH_HIP(hipEventRecord(s->ev0, s->idx->stream));
+    RH_HIP(hipEventRecord(s->ev0, s->stream));
     RH_TRY(shard_enqueue_step(s, true));
-    RH_HIP(hipEventRecord(s->ev1, s->idx->stream));
+    RH_HIP(hipEventRecord(s->ev1, s->stream));
     uint32_t live = 0;
-    RH_HIP(hipMemcpyAsync(&live, s->d_req + (size_t)s->nq * s->W, 4, hipMemcpyDeviceToHost, s->idx->stream));
-    RH_HIP(hipStreamSynchronize(s->idx->stream));
+    RH_HIP(hipMemcpyAsync(&live, s->d_req + (size_t)s->nq * s->W, 4, hipMemcpyDeviceToHost, s->stream));
+    RH_HIP(hipStreamSynchronize(s->stream));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->step_ms += ms;
     s->steps++;
-    if (out_live) *out_live = live;
+    // (a traversal that failed on the device keeps the rank "live" for its peers: they all stop at the next look)
+    if (out_live) *out_live = (live & SH_POISON) ? (live & ~SH_POISON) + 1u : live;
     return RADHIP_OK;
 }
 extern "C" int radhip_shard_get_requests(radhip_shard_t *s, uint32_t *host) {
@@ -634,10 +778,10 @@ extern "C" int radhip_shard_evaluate(radhip_shard_t *s) {
     if (!s) RH_FAIL(RADHIP_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_TRY(shard_check(s));
-    RH_HIP(hipEventRecord(s->ev0, s->idx->stream));
+    RH_HIP(hipEventRecord(s->ev0, s->stream));
     RH_TRY(shard_enqueue_eval(s));
-    RH_HIP(hipEventRecord(s->ev1, s->idx->stream));
-    RH_HIP(hipStreamSynchronize(s->idx->stream));
+    RH_HIP(hipEventRecord(s->ev1, s->stream));
+    RH_HIP(hipStreamSynchronize(s->stream));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->eval_ms += ms;
     return RADHIP_OK;
@@ -659,62 +803,141 @@ extern "C" int radhip_shard_set_scores_in(radhip_shard_t *s, const uint32_t *hos
 
 static int shard_first_error(radhip_shard *s);
 
-// ---- the product loop: kernels and RCCL collectives on one stream, device buffers end to end ------------
-extern "C" int radhip_shard_run(radhip_shard_t *s, radhip_comm_t *comm, uint64_t max_steps, uint64_t *out_steps) {
-    if (!s || !comm) RH_FAIL(RADHIP_E_INVALID, "null argument");
-    if (comm->world != s->world || comm->rank != s->rank) RH_FAIL(RADHIP_E_INVALID, "communicator and shard disagree on rank / world");
-    std::unique_lock<std::mutex> lk(s->idx->mu);
-    RH_TRY(shard_check(s));
-    hipStream_t st = s->idx->stream;
-    const size_t per_rank = (size_t)s->nq * s->W;
-    std::vector<uint32_t> live(s->world);
+// wait for a stream with a deadline: a peer that died or left the loop must not hang this rank in a collective
+// for ever (RADHIP_SHARD_TIMEOUT_S, default 300 s per look; a look normally takes well under a second)
+static int shard_sync(hipStream_t st) {
+    static const double limit = [] { const char *e = getenv("RADHIP_SHARD_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 300.0; }();
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return RADHIP_OK;
+        if (e != hipErrorNotReady) RH_FAIL(RADHIP_E_HIP, "the sharded loop's stream failed: %s", hipGetErrorString(e));
+        if (++spins < 4096u) continue;                       // a look every few steps: the first answers come in microseconds
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if ((spins & 1023u) == 0u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+            RH_FAIL(RADHIP_E_COMM, "no answer from the sharded loop's stream for %.0f s (a peer left a collective?)", limit);
+    }
+}
+
+// ---- the product loop: kernels and RCCL collectives, device buffers end to end.  One group of traversals on one
+// stream, or TWO groups on two streams with two communicators (radhip_shard_run_pair): a frontier step is latency-
+// bound end to end (a step kernel that ends with its slowest pop, then two small collectives), so the second group's
+// step kernel runs while the first group's collectives are on the wire and the other way round.
+static int shard_run_groups(radhip_shard **S, radhip_comm **C, int ng, uint64_t max_steps, uint64_t *out_steps) {
+    radhip_index *idx = S[0]->idx;
+    for (int g = 0; g < ng; ++g) {
+        if (!S[g] || !C[g]) RH_FAIL(RADHIP_E_INVALID, "null argument");
+        if (S[g]->idx != idx) RH_FAIL(RADHIP_E_INVALID, "the groups of one loop share one index");
+        if (C[g]->world != S[g]->world || C[g]->rank != S[g]->rank) RH_FAIL(RADHIP_E_INVALID, "communicator and shard disagree on rank / world");
+        if (ng > 1 && S[g]->wave) RH_FAIL(RADHIP_E_INVALID, "paired groups need the thread engine");
+        for (int h = 0; h < g; ++h)
+            if (S[h]->stream == S[g]->stream || C[h] == C[g]) RH_FAIL(RADHIP_E_INVALID, "paired groups need a stream and a communicator each (RADHIP_SHARD_OWN_STREAM)");
+    }
+    std::unique_lock<std::mutex> lk(idx->mu);
+    for (int g = 0; g < ng; ++g) RH_TRY(shard_check(S[g]));
+    const int world = S[0]->world;
+    std::vector<uint32_t> live((size_t)world * ng);
     uint64_t steps = 0;
-    // RADHIP_SHARD_TIMING=1: per-phase device time of the loop (diagnostic; adds five event records per step)
-    const bool phases = getenv("RADHIP_SHARD_TIMING") != nullptr;
+    // RADHIP_SHARD_TIMING=1: per-phase device time of the loop (diagnostic; one group only; adds five event records per step)
+    const bool phases = ng == 1 && getenv("RADHIP_SHARD_TIMING") != nullptr;
     hipEvent_t pe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double pms[4] = {0, 0, 0, 0};
     if (phases) for (auto &e : pe) (void)hipEventCreate(&e);
-    RH_HIP(hipEventRecord(s->ev0, st));
-    for (;;) {
-        if (phases) (void)hipEventRecord(pe[0], st);
-        RH_TRY(shard_enqueue_step(s, steps == 0));
-        if (phases) (void)hipEventRecord(pe[1], st);
-        RH_TRY(rh_comm_allgather_dev(comm, s->d_req, s->d_req_all, per_rank + 16, st));
-        if (phases) (void)hipEventRecord(pe[2], st);
-        RH_TRY(shard_enqueue_eval(s));
-        if (phases) (void)hipEventRecord(pe[3], st);
-        RH_TRY(rh_comm_reduce_scatter_u32_dev(comm, s->d_out, s->d_in, per_rank, st));
-        if (phases) (void)hipEventRecord(pe[4], st);
-        steps++;
-        s->exchanged_bytes += (uint64_t)s->world * (per_rank + 16) * 4 + (uint64_t)s->world * per_rank * 4;
-        // The live counts of all ranks travel behind the candidates, so every rank sees the same numbers and stops
-        // at the same step.  The host looks at them (a stream synchronisation) only every fourth step — and every
-        // 64th while no traversal can have reached n_to_score yet (a step scores W nodes at most): a step of
-        // finished traversals is a no-op, so looking late costs a few empty steps, never a different result.
-        const bool last = max_steps && steps >= max_steps;
-        const bool look = phases || last || (steps % (steps * s->W < s->n_to_score ? 64u : 4u)) == 0u;
-        if (!look) continue;
-        for (int r = 0; r < s->world; ++r)
-            RH_HIP(hipMemcpyAsync(&live[r], s->d_req_all + (size_t)r * (per_rank + 16) + per_rank, 4, hipMemcpyDeviceToHost, st));
-        RH_HIP(hipStreamSynchronize(st));
-        if (phases) for (int i = 0; i < 4; ++i) { float m = 0.f; if (hipEventElapsedTime(&m, pe[i], pe[i + 1]) == hipSuccess) pms[i] += m; }
-        uint64_t tot = 0;
-        for (int r = 0; r < s->world; ++r) tot += live[r];
-        if (tot == 0 || last) break;
-    }
-    RH_HIP(hipEventRecord(s->ev1, st));
-    RH_HIP(hipStreamSynchronize(st));
+    long long fail_at = -1;   // test hook: a host-side failure in the middle of the loop
+    if (const char *e = getenv("RADHIP_SHARD_TEST_FAIL_AT")) fail_at = atoll(e);
+    uint32_t poisoned_by = 0xFFFFFFFFu;
+    auto loop = [&]() -> int {
+        for (int g = 0; g < ng; ++g) RH_HIP(hipEventRecord(S[g]->ev0, S[g]->stream));
+        for (;;) {
+            if (fail_at >= 0 && (long long)steps == fail_at) RH_FAIL(RADHIP_E_HIP, "injected failure at step %lld (RADHIP_SHARD_TEST_FAIL_AT)", fail_at);
+            for (int g = 0; g < ng; ++g) {
+                radhip_shard *s = S[g];
+                hipStream_t st = s->stream;
+                const size_t per_rank = (size_t)s->nq * s->W;
+                if (phases) (void)hipEventRecord(pe[0], st);
+                RH_TRY(shard_enqueue_step(s, steps == 0));
+                if (phases) (void)hipEventRecord(pe[1], st);
+                RH_TRY(rh_comm_allgather_dev(C[g], s->d_req, s->d_req_all, per_rank + 16, st));
+                if (phases) (void)hipEventRecord(pe[2], st);
+                RH_TRY(shard_enqueue_eval(s));
+                if (phases) (void)hipEventRecord(pe[3], st);
+                RH_TRY(rh_comm_reduce_scatter_u32_dev(C[g], s->d_out, s->d_in, per_rank, st));
+                if (phases) (void)hipEventRecord(pe[4], st);
+                s->exchanged_bytes += (uint64_t)s->world * (per_rank + 16) * 4 + (uint64_t)s->world * per_rank * 4;
+            }
+            steps++;
+            // The live words of all ranks travel behind the candidates, so every rank sees the same numbers and stops
+            // at the same step.  The host looks at them (a stream synchronisation) only every fourth step — and every
+            // 64th while no traversal can have reached n_to_score yet (a step scores W nodes at most): a step of
+            // finished traversals is a no-op, so looking late costs a few empty steps, never a different result.
+            const bool last = max_steps && steps >= max_steps;
+            const bool look = phases || last || (steps % (steps * S[0]->W < S[0]->n_to_score ? 64u : 4u)) == 0u;
+            if (!look) continue;
+            for (int g = 0; g < ng; ++g) {
+                const size_t per_rank = (size_t)S[g]->nq * S[g]->W;
+                for (int r = 0; r < world; ++r)
+                    RH_HIP(hipMemcpyAsync(&live[(size_t)g * world + r], S[g]->d_req_all + (size_t)r * (per_rank + 16) + per_rank, 4, hipMemcpyDeviceToHost, S[g]->stream));
+            }
+            for (int g = 0; g < ng; ++g) RH_TRY(shard_sync(S[g]->stream));
+            if (phases) for (int i = 0; i < 4; ++i) { float m = 0.f; if (hipEventElapsedTime(&m, pe[i], pe[i + 1]) == hipSuccess) pms[i] += m; }
+            uint64_t tot = 0;
+            for (size_t i = 0; i < live.size(); ++i) {
+                if ((live[i] & SH_POISON) && poisoned_by == 0xFFFFFFFFu) poisoned_by = (uint32_t)(i % (size_t)world);
+                tot += live[i] & ~SH_POISON;
+            }
+            if (poisoned_by != 0xFFFFFFFFu || tot == 0 || last) break;
+        }
+        for (int g = 0; g < ng; ++g) RH_HIP(hipEventRecord(S[g]->ev1, S[g]->stream));
+        for (int g = 0; g < ng; ++g) RH_TRY(shard_sync(S[g]->stream));
+        return RADHIP_OK;
+    };
+    const int rc = loop();
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->step_ms += ms;
+    if (rc == RADHIP_OK) for (int g = 0; g < ng; ++g) if (hipEventElapsedTime(&ms, S[g]->ev0, S[g]->ev1) == hipSuccess) S[g]->step_ms += ms;
     if (phases) {
-        fprintf(stderr, "[shard] %llu steps, device ms per step: step kernel %.4f, all-gather %.4f, evaluation %.4f, reduce-scatter %.4f; whole loop %.4f\n",
-                (unsigned long long)steps, pms[0] / steps, pms[1] / steps, pms[2] / steps, pms[3] / steps, ms / steps);
+        if (rc == RADHIP_OK && steps)
+            fprintf(stderr, "[shard] %llu steps, device ms per step: step kernel %.4f, all-gather %.4f, evaluation %.4f, reduce-scatter %.4f; whole loop %.4f\n",
+                    (unsigned long long)steps, pms[0] / steps, pms[1] / steps, pms[2] / steps, pms[3] / steps, ms / steps);
         for (auto &e : pe) if (e) (void)hipEventDestroy(e);
     }
-    s->steps += steps;
+    for (int g = 0; g < ng; ++g) S[g]->steps += steps;
     if (out_steps) *out_steps = steps;
+    if (rc != RADHIP_OK) {
+        // This rank leaves the loop alone: its peers are (or will be) inside a collective it never enters.  Abort the
+        // communicators, so that their collectives fail (or their look times out) instead of waiting for ever; the
+        // stream is drained first so that nothing of this rank is left half-enqueued.
+        char msg[400];
+        snprintf(msg, sizeof msg, "%s", radhip_last_error());
+        for (int g = 0; g < ng; ++g) { (void)hipStreamSynchronize(S[g]->stream); if (C[g]->world > 1) (void)rh_comm_abort(C[g]); }
+        radhip_set_error("radhip_shard_run left the loop after %llu steps: %s%s", (unsigned long long)steps, msg,
+                         world > 1 ? " (communicator aborted: the peers' collectives fail instead of hanging)" : "");
+        return rc;
+    }
     lk.unlock();
-    return shard_first_error(s);
+    if (poisoned_by != 0xFFFFFFFFu) {
+        // every rank saw the same word at the same step and left together: no abort needed.  The rank that owns the
+        // failed traversal reports which one; the others report the remote failure.
+        for (int g = 0; g < ng; ++g) { const int e = shard_first_error(S[g]); if (e != RADHIP_OK) return e; }
+        RH_FAIL(RADHIP_E_CAPACITY, "a traversal of rank %u overflowed a fixed-capacity device structure: the loop ended on every rank after %llu steps",
+                poisoned_by, (unsigned long long)steps);
+    }
+    for (int g = 0; g < ng; ++g) RH_TRY(shard_first_error(S[g]));
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_shard_run(radhip_shard_t *s, radhip_comm_t *comm, uint64_t max_steps, uint64_t *out_steps) {
+    if (!s || !comm) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    radhip_shard *S[1] = {s};
+    radhip_comm *C[1] = {comm};
+    return shard_run_groups(S, C, 1, max_steps, out_steps);
+}
+extern "C" int radhip_shard_run_pair(radhip_shard_t *a, radhip_comm_t *comm_a, radhip_shard_t *b, radhip_comm_t *comm_b,
+                                     uint64_t max_steps, uint64_t *out_steps) {
+    if (!a || !b || !comm_a || !comm_b) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    radhip_shard *S[2] = {a, b};
+    radhip_comm *C[2] = {comm_a, comm_b};
+    return shard_run_groups(S, C, 2, max_steps, out_steps);
 }
 
 // a device-side failure of any local traversal is an error of the call

@@ -94,6 +94,10 @@ struct TravParams {
     const uint4 *queries;
     unsigned long long *ht;  // {slot | val<<32}
     uint32_t ht_log2;
+    // bucket table (trav4_kernel<.., BT = true>, traverse4.inc): per traversal 2^bt_log2 buckets of four u32 entries
+    // (slot + 1) | epoch << bt_sbits | v0 << 31; epochs 1 .. 2^(31 - bt_sbits) - 1, 0 = cleared
+    uint32_t *bt;
+    uint32_t bt_log2, bt_sbits;
     unsigned long long *ut;
     uint32_t ut_log2;
     // grouped visited/scored table (GT kernels; needs the index's graph-locality layout, layout.hip):
@@ -707,6 +711,9 @@ struct radhip_traversal {
     bool fresh_tables = true;   // tables not cleared yet (first upload)
     bool use4 = false;   // trav4_kernel (four traversals per wave) when every adjacency row is <= 16 wide
     bool use_gt = false; // grouped visited/scored table (needs the index's graph-locality layout)
+    bool use_bt = false; // bucket table: 16-B buckets of four entries, one request per probe (trav4_kernel's default)
+    size_t bt_bytes = 0;
+    uint32_t epoch_max = EPOCH_LIMIT - 1u;   // last usable epoch of the table in use
     bool sharded = false; // the row-sharded form of trav4_kernel (shard.hip): stepped, never run()
     size_t gt_bytes = 0;
     uint64_t graph_gen = 0;   // generation of the index this state was sized for
@@ -748,11 +755,14 @@ static int trav_upload_queries(radhip_traversal *t, const uint8_t *queries) {
     }
     RH_HIP(hipMemcpyAsync(t->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, idx->stream));
     RH_HIP(hipMemcpyAsync(t->P.hdr, hdr.data(), t->hdr_bytes, hipMemcpyHostToDevice, idx->stream));
-    if (t->fresh_tables || ++t->P.epoch >= EPOCH_LIMIT) {   // first use, or epoch space exhausted: really clear
-        t->P.epoch = 0;
+    if (t->fresh_tables || ++t->P.epoch > t->epoch_max) {   // first use, or epoch space exhausted: really clear
+        // (the bucket table's cleared state is 0 = epoch 0, so its live epochs start at 1; the other tables clear to
+        // all-ones = epoch 0x7F and count from 0.  At 1B rows a bucket entry has one epoch bit: cleared every batch.)
+        t->P.epoch = t->use_bt ? 1u : 0u;
         t->fresh_tables = false;
         if (t->P.ht) RH_HIP(hipMemsetAsync(t->P.ht, 0xFF, t->ht_bytes, idx->stream));
         if (t->P.gt) RH_HIP(hipMemsetAsync(t->P.gt, 0xFF, t->gt_bytes, idx->stream));
+        if (t->P.bt) RH_HIP(hipMemsetAsync(t->P.bt, 0x00, t->bt_bytes, idx->stream));
         RH_HIP(hipMemsetAsync(t->P.ut, 0x00, t->ut_bytes, idx->stream));
     }
     RH_HIP(hipStreamSynchronize(idx->stream));
@@ -768,6 +778,7 @@ extern "C" int radhip_traversal_destroy(radhip_traversal_t *t) {
     if (t->P.hdr) (void)hipFree(t->P.hdr);
     if (t->P.ht) (void)hipFree(t->P.ht);
     if (t->P.gt) (void)hipFree(t->P.gt);
+    if (t->P.bt) (void)hipFree(t->P.bt);
     if (t->P.ut) (void)hipFree(t->P.ut);
     if (t->P.scored) (void)hipFree(t->P.scored);
     if (t->P.pq) (void)hipFree(t->P.pq);
@@ -869,11 +880,20 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
         const bool can = idx->layout_valid && idx->d_adjx0 && t->use4 && gt_log2 <= 17 && !sharded;
         t->use_gt = can && force_group;
         P.gt_log2 = gt_log2;
+        // Bucket table: trav4_kernel's default (RADHIP_TABLE=hash keeps the one-entry-per-probe table, for A/B runs).
+        // 2.5 entries per scored node at least (load <= 0.4: a probe needs a second bucket once in ~100).
+        const bool force_hash = e && e[0] == 'h';
+        t->use_bt = t->use4 && !t->use_gt && !sharded && !force_hash;
+        P.bt_log2 = std::max<uint32_t>(6, log2_ceil((scored_cap * 5 + 7) / 8));
+        P.bt_sbits = std::max<uint32_t>(8, log2_ceil(idx->g_n + 2));
+        if (P.bt_sbits > 30 || P.bt_log2 > 28) t->use_bt = false;
+        if (t->use_bt) t->epoch_max = (1u << (31u - P.bt_sbits)) - 1u;
         P.adjx0 = idx->d_adjx0; P.adjxU = idx->d_adjxU; P.topx = idx->d_topx; P.lid = idx->d_lid;
     }
     t->hdr_bytes = (size_t)nq * sizeof(TravHeader);
     t->gt_bytes = t->use_gt ? ((size_t)nq << (P.gt_log2 + 4)) * 8 : 0;
-    t->ht_bytes = t->use_gt ? 0 : ((size_t)nq << ht_log2) * 8;
+    t->bt_bytes = t->use_bt ? ((size_t)nq << (P.bt_log2 + 2)) * 4 : 0;
+    t->ht_bytes = (t->use_gt || t->use_bt) ? 0 : ((size_t)nq << ht_log2) * 8;
     t->ut_bytes = ((size_t)nq << ut_log2) * 8;
     t->scored_bytes = (size_t)nq * scored_cap * sizeof(uint2);
     t->pq_bytes = (size_t)nq * pq_cap * 8;
@@ -897,6 +917,7 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
     if (rc == 0) RH_A(P.hdr, t->hdr_bytes);
     if (rc == 0 && t->ht_bytes) RH_A(P.ht, t->ht_bytes);
     if (rc == 0 && t->gt_bytes) RH_A(P.gt, t->gt_bytes);
+    if (rc == 0 && t->bt_bytes) RH_A(P.bt, t->bt_bytes);
     if (rc == 0) RH_A(P.ut, t->ut_bytes);
     if (rc == 0) RH_A(P.scored, t->scored_bytes);
     if (rc == 0) RH_A(P.pq, t->pq_bytes);
@@ -979,10 +1000,13 @@ static int trav_launch(radhip_traversal *t) {
     }
 #define RH_K4G(LPR) trav4_kernel<LPR, true>
 #define RH_K4H(LPR) trav4_kernel<LPR, false>
+#define RH_K4B(LPR) trav4_kernel<LPR, false, false, true>
 #define RH_K1H(LPR) trav_kernel<LPR>
     if (t->use4 && t->use_gt) { RH_TRAV_CASES(RH_K4G, (t->nq + 3u) / 4u) }
+    else if (t->use4 && t->use_bt) { RH_TRAV_CASES(RH_K4B, (t->nq + 3u) / 4u) }
     else if (t->use4) { RH_TRAV_CASES(RH_K4H, (t->nq + 3u) / 4u) }
     else { RH_TRAV_CASES(RH_K1H, t->nq) }
+#undef RH_K4B
 #undef RH_K4G
 #undef RH_K4H
 #undef RH_K1H
@@ -1345,5 +1369,5 @@ extern "C" int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t 
 // 4 = trav4_kernel (four traversals per wavefront), 1 = trav_kernel
 extern "C" int radhip_traversal_kernel(const radhip_traversal_t *t) { return t ? (t->use4 ? 4 : 1) : 0; }
 // 1 = grouped visited/scored table (2 bits per node, keyed by the graph-locality layout), 0 = per-slot hash table
-extern "C" int radhip_traversal_table(const radhip_traversal_t *t) { return t ? (t->use_gt ? 1 : 0) : -1; }
+extern "C" int radhip_traversal_table(const radhip_traversal_t *t) { return t ? (t->use_gt ? 1 : t->use_bt ? 2 : 0) : -1; }
 

@@ -64,6 +64,26 @@ class DeviceIndex:
         check(self._L.radhip_index_synth_vectors(self._h, n, first_row,
                                                  n if n_total is None else n_total, seed, mode))
 
+    def load_vectors_shard(self, rows: np.ndarray, first: int, n_total: int) -> None:
+        """One rank's rows only: `rows` are slots [first, first + len(rows)) of a corpus of n_total rows.  The
+        index never holds the rest; only the sharded traversal (DeviceShard) reads its fingerprints."""
+        rows = _lib.as_rows(rows, self.row_bytes)
+        check(self._L.radhip_index_load_vectors_shard(self._h, ptr(rows), first, rows.shape[0], n_total))
+
+    def synth_vectors_shard(self, count: int, first_row: int, n_total: int, seed: int, mode: int = 1) -> None:
+        """Rows [first_row, first_row + count) of the closed-form corpus of n_total rows as a shard: they keep
+        their global slots, the rest of the corpus never exists on this device."""
+        check(self._L.radhip_index_synth_vectors_shard(self._h, count, first_row, n_total, seed, mode))
+
+    def link_resident(self, seed: int = 0, max_batch: int = 4096) -> None:
+        """Link the rows that are already resident (load_vectors / synth_vectors) into the graph, exactly as
+        add_rows would have — without a host copy of the corpus going through the call."""
+        check(self._L.radhip_index_link_resident(self._h, seed, max_batch))
+
+    def broadcast_graph(self, comm: "RcclComm", root: int = 0) -> None:
+        """The adjacency of `root` on every rank (ncclBroadcast of the device arrays over xGMI)."""
+        check(self._L.radhip_index_broadcast_graph(self._h, comm._h, root))
+
     def read_vectors(self, first: int, count: int) -> np.ndarray:
         out = np.empty((count, self.row_bytes), np.uint8)
         check(self._L.radhip_index_read_vectors(self._h, first, count, ptr(out)))
@@ -288,8 +308,9 @@ class DeviceTraversal:
 
     @property
     def table(self) -> str:
-        """'grouped' (2 bits per node, keyed by the index's graph-locality layout) or 'hash' (one entry per node)."""
-        return "grouped" if int(self._L.radhip_traversal_table(self._h)) == 1 else "hash"
+        """'bucket' (16-B buckets of four entries, one request per probe: the four-per-wavefront kernel's default),
+        'grouped' (2 bits per node, keyed by the index's graph-locality layout) or 'hash' (one 8-byte entry per probe)."""
+        return {1: "grouped", 2: "bucket"}.get(int(self._L.radhip_traversal_table(self._h)), "hash")
 
     @property
     def kernel(self) -> str:
@@ -303,7 +324,7 @@ class DeviceShard:
     nq traversals of the batch.  `queries_all` is [world * nq, row_bytes], rank-major, the same on every rank."""
 
     def __init__(self, index: DeviceIndex, rank: int, world: int, row_first: int, row_count: int,
-                 queries_all: np.ndarray, n_to_score: int, log_pops: bool = False):
+                 queries_all: np.ndarray, n_to_score: int, log_pops: bool = False, own_stream: bool = False):
         self._L = _lib.lib()
         self.index = index
         q = _lib.as_rows(queries_all, index.row_bytes, "queries_all")
@@ -311,8 +332,9 @@ class DeviceShard:
             raise ValueError("queries_all must hold world * nq rows")
         self.rank, self.world, self.nq = int(rank), int(world), q.shape[0] // world
         self._h = C.c_void_p()
+        flags = (_lib.TRAV_LOG_POPS if log_pops else 0) | (_lib.SHARD_OWN_STREAM if own_stream else 0)
         check(self._L.radhip_shard_create(index._h, rank, world, row_first, row_count, ptr(q), self.nq, int(n_to_score),
-                                          _lib.TRAV_LOG_POPS if log_pops else 0, C.byref(self._h)))
+                                          flags, C.byref(self._h)))
         self.width = int(self._L.radhip_shard_width(self._h))
         self.engine = "wave" if int(self._L.radhip_shard_engine(self._h)) == 1 else "thread"
 
@@ -338,6 +360,20 @@ class DeviceShard:
         steps = C.c_uint64(0)
         check(self._L.radhip_shard_run(self._h, comm._h, max_steps, C.byref(steps)))
         return steps.value
+
+    def run_pair(self, comm: "RcclComm", other: "DeviceShard", other_comm: "RcclComm", max_steps: int = 0) -> int:
+        """The product loop for two groups of traversals at once (self on the index's stream, `other` created
+        with own_stream=True, a communicator each): one group's step kernel overlaps the other's collectives."""
+        steps = C.c_uint64(0)
+        check(self._L.radhip_shard_run_pair(self._h, comm._h, other._h, other_comm._h, max_steps, C.byref(steps)))
+        return steps.value
+
+    def speculation(self):
+        """(depth, speculative scores requested, of which used, expansions finished from them)"""
+        d = C.c_uint32(0)
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(self._L.radhip_shard_speculation(self._h, C.byref(d), C.byref(a), C.byref(b), C.byref(c)))
+        return d.value, a.value, b.value, c.value
 
     # -- host-staged pieces (the `local` engine of rad_amd.sharded.RowShardedTraversal)
     def step(self, scores_in: np.ndarray):
@@ -407,6 +443,15 @@ class RcclComm:
         self.rank, self.world = rank, world
         idb = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         check(self._L.radhip_comm_create(rank, world, idb, device, C.byref(self._h)))
+
+    def info(self) -> dict:
+        """What the communicator really spans, from RCCL itself: version, ncclCommCount, ncclCommUserRank, and
+        the PCI bus id of the device this rank drives."""
+        out = _lib.CommInfo()
+        check(self._L.radhip_comm_info(self._h, C.byref(out)))
+        v = int(out.rccl_version)
+        return {"rccl_version": f"{v // 10000}.{(v // 100) % 100}.{v % 100}", "rccl_version_code": v, "comm_count": int(out.comm_count),
+                "comm_rank": int(out.comm_rank), "device": int(out.device), "pci_bus_id": out.pci_bus_id.decode("ascii", "replace")}
 
     def allgather_u64(self, local: np.ndarray) -> np.ndarray:
         """[count] u64 per rank -> [world, count]"""

@@ -143,12 +143,18 @@ def _row_sharded_setup(oracle, n, nts, world, nq, mode=2, seed=7):
     return X, g, full, Qall
 
 
-@pytest.fixture(params=["wave", "thread"])
+@pytest.fixture(params=["wave", "thread", "thread-spec0", "thread-spec1"])
 def engine(request, monkeypatch):
     """both step kernels of shard.hip: the single-GPU traversal kernel cut at the fingerprint read, and the
-    thread-per-traversal restatement of the oracle's stepper"""
-    monkeypatch.setenv("RADHIP_SHARD_ENGINE", request.param)
-    return request.param
+    thread-per-traversal restatement of the oracle's stepper — the latter without speculation and with one or
+    two (the default) queue heads expanded speculatively per step: the committed state must not depend on it"""
+    name, _, spec = request.param.partition("-spec")
+    monkeypatch.setenv("RADHIP_SHARD_ENGINE", name)
+    if spec:
+        monkeypatch.setenv("RADHIP_SHARD_SPEC", spec)
+    else:
+        monkeypatch.delenv("RADHIP_SHARD_SPEC", raising=False)
+    return name
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -221,3 +227,189 @@ def test_sharded_index_refuses_whole_corpus_entry_points(gpu, oracle):
                  lambda: full.keep_rows(0, 10)):
         with pytest.raises(RadHipError):
             call()
+
+
+# ------------------------------------------------------------------ shard-native setup
+def _check_against_oracle(oracle, shards, g, X, Qall, nq, nts):
+    for r, sh in enumerate(shards):
+        st = sh.stats()
+        assert set(st.status.tolist()) <= {1, 2}
+        for q in range(nq):
+            want = oracle.rad_traverse(g, X, Qall[r * nq + q], nts)
+            s_, a, o = sh.results(q)
+            nodes, lv = sh.pop_log(q)
+            assert np.array_equal(s_, want.slots), (r, q)
+            assert np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt)
+            assert np.array_equal(nodes, want.pop_nodes) and np.array_equal(lv, want.pop_levels)
+            assert st.n_pops[q] == want.n_pops and st.n_nbr[q] == want.n_nbr
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_created_with_only_their_rows(gpu, oracle, world, monkeypatch):
+    """Every rank's index is CREATED with its rows only (radhip_index_load_vectors_shard): no rank ever allocates,
+    stages or uploads another rank's rows; the graph over the whole corpus comes from load_graph.  Results equal
+    the oracle's traversal of the whole corpus."""
+    from rad_amd._lib import RadHipError
+    from rad_amd.device import DeviceIndex, DeviceShard
+    monkeypatch.delenv("RADHIP_SHARD_ENGINE", raising=False)
+    n, nts, nq = 20000, 1500, 4
+    X, g, full, Qall = _row_sharded_setup(oracle, n, nts, world, nq)
+    full_bytes = full.info().device_bytes
+    full.close()
+    rows = n // world
+    shards, idxs = [], []
+    for r in range(world):
+        first = r * rows
+        count = rows if r < world - 1 else n - first
+        idx = DeviceIndex(1024, 8, 16, 48)
+        idx.load_vectors_shard(X[first:first + count], first, n)
+        idx.load_graph(g.levels, g.adj0, g.upper_row, g.adjU, g.max_level, g.entry)
+        sh = DeviceShard(idx, r, world, first, count, Qall, nts, log_pops=True)
+        inf = idx.info()
+        assert inf.sharded == 1 and inf.shard_first == first and inf.shard_rows == count and inf.n == n
+        # rows of this rank + the whole adjacency, nothing else: well below a full index
+        assert inf.device_bytes <= count * 128 + (full_bytes - n * 128) + 4096
+        with pytest.raises(RadHipError):
+            idx.read_vectors(0, 1)                       # whole-corpus entry points refuse a shard
+        with pytest.raises(RadHipError):
+            DeviceShard(idx, r, world, 0, n, Qall, nts)  # rows it does not hold
+        idxs.append(idx); shards.append(sh)
+    assert _lockstep(shards) > 10
+    _check_against_oracle(oracle, shards, g, X, Qall, nq, nts)
+
+
+def test_synthetic_shards_and_closed_form_graph(gpu, oracle, monkeypatch):
+    """config[3]'s setup in small: every rank generates ITS rows of the closed-form corpus on the device
+    (radhip_index_synth_vectors_shard) and the closed-form graph over all n_total nodes (no row is read for it) —
+    no collective, no host copy, nothing of the other ranks' rows."""
+    from rad_amd.device import DeviceIndex, DeviceShard
+    monkeypatch.delenv("RADHIP_SHARD_ENGINE", raising=False)
+    n, nts, nq, world = 30000, 2000, 3, 3
+    X = oracle.synth_rows(0, n, n, 1024, 1234, 1)
+    g = oracle.synth_graph(n, 8, 16, 99)
+    Qall = X[np.random.default_rng(5).integers(0, n, world * nq)].copy()
+    rows = n // world
+    shards, idxs = [], []
+    for r in range(world):
+        first = r * rows
+        count = rows if r < world - 1 else n - first
+        idx = DeviceIndex(1024, 8, 16, 64)
+        idx.synth_vectors_shard(count, first, n, seed=1234, mode=1)
+        idx.synth_graph(seed=99)
+        inf = idx.info()
+        assert inf.n == n and inf.shard_rows == count and inf.max_level == g.max_level
+        lv, a0, ur, aU = idx.read_graph()
+        assert np.array_equal(a0, g.adj0) and np.array_equal(lv, g.levels) and np.array_equal(aU, g.adjU)
+        idxs.append(idx)
+        shards.append(DeviceShard(idx, r, world, first, count, Qall, nts, log_pops=True))
+    assert _lockstep(shards) > 10
+    _check_against_oracle(oracle, shards, g, X, Qall, nq, nts)
+
+
+def test_link_resident_equals_add(gpu, oracle):
+    """radhip_index_link_resident (rows already in HBM) builds the graph radhip_index_add builds from host rows."""
+    from rad_amd.device import DeviceIndex
+    n = 40000
+    X = oracle.synth_rows(0, n, n, 1024, 20260101, 2)
+    a = DeviceIndex(1024, 8, 16, 48)
+    a.add_rows(X, seed=777, max_batch=1024)
+    b = DeviceIndex(1024, 8, 16, 48)
+    b.synth_vectors(n, seed=20260101, mode=2)
+    b.link_resident(seed=777, max_batch=1024)
+    ga, gb = a.read_graph(), b.read_graph()
+    for x, y in zip(ga, gb):
+        assert np.array_equal(x, y)
+    ia, ib = a.info(), b.info()
+    assert (ia.max_level, ia.entry, ia.n) == (ib.max_level, ib.entry, ib.n)
+    # extending: half by add, the rest resident
+    c = DeviceIndex(1024, 8, 16, 48)
+    c.load_vectors(X)
+    c.link_resident(seed=777, max_batch=1024)
+    for x, y in zip(ga, c.read_graph()):
+        assert np.array_equal(x, y)
+
+
+def test_speculation_cuts_steps_not_results(gpu, oracle, monkeypatch):
+    """Speculative score prefetch: fewer frontier steps, identical committed state."""
+    from rad_amd.device import DeviceShard, RcclComm
+    monkeypatch.setenv("RADHIP_SHARD_ENGINE", "thread")
+    n, nq, nts = 60000, 16, 6000
+    X, g, full, Qall = _row_sharded_setup(oracle, n, nts, 1, nq, mode=2, seed=11)
+    comm = RcclComm(0, 1, RcclComm.unique_id(), 0)
+    steps, res = {}, {}
+    for spec in (0, 1, 2):
+        monkeypatch.setenv("RADHIP_SHARD_SPEC", str(spec))
+        sh = DeviceShard(full, 0, 1, 0, n, Qall, nts, log_pops=True)
+        assert sh.width == 16 * (1 + spec)
+        steps[spec] = sh.run(comm)
+        res[spec] = [sh.results(q) + sh.pop_log(q) for q in range(nq)]
+        depth, asked, used, hits = sh.speculation()
+        assert depth == spec
+        if spec:
+            assert asked > 0 and 0 < used <= asked and hits > 0
+        else:
+            assert asked == used == hits == 0
+        sh.close()
+    for q in range(nq):
+        want = oracle.rad_traverse(g, X, Qall[q], nts)
+        for spec in (0, 1, 2):
+            s_, a, o, nodes, lv = res[spec][q]
+            assert np.array_equal(s_, want.slots) and np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt)
+            assert np.array_equal(nodes, want.pop_nodes) and np.array_equal(lv, want.pop_levels)
+    assert steps[1] < steps[0] * 0.8 and steps[2] <= steps[1], steps
+
+
+def test_pair_of_groups_on_two_streams(gpu, oracle, monkeypatch):
+    """radhip_shard_run_pair: two groups of traversals, each with its own stream and communicator, stepped in
+    one loop; every group's results are those of its own run."""
+    from rad_amd.device import DeviceShard, RcclComm
+    monkeypatch.delenv("RADHIP_SHARD_ENGINE", raising=False)
+    n, nq, nts = 30000, 6, 3000
+    X, g, full, Qall = _row_sharded_setup(oracle, n, nts, 2, nq, mode=2, seed=21)
+    ca = RcclComm(0, 1, RcclComm.unique_id(), 0)
+    cb = RcclComm(0, 1, RcclComm.unique_id(), 0)
+    a = DeviceShard(full, 0, 1, 0, n, Qall[:nq], nts, log_pops=True)
+    b = DeviceShard(full, 0, 1, 0, n, Qall[nq:], nts // 2, log_pops=True, own_stream=True)
+    steps = a.run_pair(ca, b, cb)
+    assert steps > 10
+    for grp, (sh, Q, t) in enumerate(((a, Qall[:nq], nts), (b, Qall[nq:], nts // 2))):
+        for q in range(nq):
+            want = oracle.rad_traverse(g, X, Q[q], t)
+            s_, aa, oo = sh.results(q)
+            nodes, lv = sh.pop_log(q)
+            assert np.array_equal(s_, want.slots), (grp, q)
+            assert np.array_equal(aa, want.and_cnt) and np.array_equal(oo, want.or_cnt)
+            assert np.array_equal(nodes, want.pop_nodes) and np.array_equal(lv, want.pop_levels)
+
+
+def test_loop_fails_safe(gpu, oracle, monkeypatch):
+    """A host-side failure in the middle of radhip_shard_run (injected) and a device-side one (a queue that is
+    too small): both return an error promptly, leak nothing that blocks the next run, and a fresh shard on the
+    same index works afterwards."""
+    from rad_amd import _lib
+    from rad_amd._lib import RadHipError
+    from rad_amd.device import DeviceShard, RcclComm
+    monkeypatch.setenv("RADHIP_SHARD_ENGINE", "thread")
+    n, nq, nts = 20000, 8, 4000
+    X, g, full, Qall = _row_sharded_setup(oracle, n, nts, 1, nq, mode=2, seed=31)
+    comm = RcclComm(0, 1, RcclComm.unique_id(), 0)
+    monkeypatch.setenv("RADHIP_SHARD_TEST_FAIL_AT", "7")
+    sh = DeviceShard(full, 0, 1, 0, n, Qall, nts)
+    with pytest.raises(RadHipError) as ei:
+        sh.run(comm)
+    assert ei.value.code == _lib.E_HIP and "injected" in str(ei.value) and "after 7 steps" in str(ei.value)
+    sh.close()
+    monkeypatch.delenv("RADHIP_SHARD_TEST_FAIL_AT")
+    monkeypatch.setenv("RADHIP_SHARD_TEST_HEAP_CAP", "96")
+    sh = DeviceShard(full, 0, 1, 0, n, Qall, nts)
+    with pytest.raises(RadHipError) as ei:
+        sh.run(comm)
+    assert ei.value.code == _lib.E_CAPACITY
+    sh.close()
+    monkeypatch.delenv("RADHIP_SHARD_TEST_HEAP_CAP")
+    sh = DeviceShard(full, 0, 1, 0, n, Qall, nts)
+    assert sh.run(comm) > 10
+    want = oracle.rad_traverse(g, X, Qall[0], nts)
+    assert np.array_equal(sh.results(0)[0], want.slots)
+    info = comm.info()
+    assert info["comm_count"] == 1 and info["comm_rank"] == 0 and info["rccl_version_code"] > 0 and ":" in info["pci_bus_id"]

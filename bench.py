@@ -80,7 +80,13 @@ def parse_args():
     ap.add_argument("--sharded-timeout", type=float, default=420.0,
                     help="seconds the sharded leg may take before the line is printed without it (a hung collective must not cost the run)")
     ap.add_argument("--sharded-nq", type=int, default=16384,
-                    help="traversals per rank and step of the sharded leg (a step costs 86 us at 8192, 89 us at 16384: the more the better; 5.5 MB of state each)")
+                    help="traversals per rank and step of the sharded leg (a step costs 86 us at 8192, 89 us at 16384: the more the better; 6.5 MB of state each)")
+    ap.add_argument("--sharded-groups", type=int, default=1, choices=[1, 2],
+                    help="groups the sharded traversals of a rank are split into: 2 = two streams and two communicators, one group's "
+                         "step kernel overlaps the other's collectives (RCCL exchange only)")
+    ap.add_argument("--sharded-reference", choices=["auto", "rank0", "none"], default="auto",
+                    help="--mode sharded: parity reference = the single-GPU kernel on rank 0, which holds the whole corpus for one "
+                         "sequential phase before it creates its shard (auto: when corpus + graph fit one GPU)")
     ap.add_argument("--exchange", choices=["rccl", "host", "gloo"], default="rccl",
                     help="sharded leg: rccl (product: device buffers, one stream) or host (rehearsal of N ranks on one GPU: "
                          "host-staged buffers over the TCP group; `gloo` is an alias)")
@@ -139,6 +145,14 @@ def cpu_model() -> str:
     return "unknown"
 
 
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """progress on stderr (the JSON line on stdout stays alone): which stage a long or failed run was in"""
+    print(f"[bench {time.perf_counter() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
 def pctl(xs, q):
     return float(np.percentile(np.asarray(xs, np.float64), q)) if len(xs) else None
 
@@ -149,21 +163,17 @@ def build_index(args, mode, device, layout=True):
     n, ndim, M = args.n, args.ndim, args.connectivity
     idx = DeviceIndex(ndim, M, 2 * M, args.expansion_add, device=device)
     idx.synth_vectors(n, seed=20260101, mode=mode)
+    note(f"corpus mode {mode}: {n} rows generated on the device")
     t_build = 0.0
     if args.graph == "synthetic" and mode == 1:
         idx.synth_graph(seed=777)
     else:
-        X = np.empty((n, idx.row_bytes), np.uint8)    # add() takes host rows, as the reference's does
-        for f in range(0, n, 4_000_000):
-            c = min(4_000_000, n - f)
-            X[f:f + c] = idx.read_vectors(f, c)
-        idx.close()
-        idx = DeviceIndex(ndim, M, 2 * M, args.expansion_add, device=device)
+        # the rows are resident already (generated on the device): they are linked where they are, no host copy
+        # of the corpus (radhip_index_link_resident == radhip_index_add of the same rows, tests/test_gpu_sharded.py)
         t_build = time.perf_counter()
-        for f in range(0, n, 5_000_000):
-            idx.add_rows(X[f:f + 5_000_000], seed=777, max_batch=16384)
+        idx.link_resident(seed=777, max_batch=16384)
         t_build = time.perf_counter() - t_build
-        del X
+        note(f"graph built in {t_build:.1f} s")
     info = None
     if layout and args.table == "group":
         info = idx.optimize_layout()
@@ -189,8 +199,10 @@ def run_traversal_leg(args, idx, batches, steps, warmup, barrier):
         st = trav.stats()
         return ms, launches, st
 
+    note(f"traversal state for {trav.nq} traversals allocated ({trav.state_bytes() / 1e9:.1f} GB, kernel {trav.kernel}, table {trav.table})")
     for w in range(warmup):
         step(w)
+    note("warm-up done")
     barrier()
     t0 = time.perf_counter()
     k_ms, k_launches, pops, evals, nbrs = [], 0, 0, 0, 0
@@ -203,8 +215,10 @@ def run_traversal_leg(args, idx, batches, steps, warmup, barrier):
         last = st
     barrier()
     elapsed = time.perf_counter() - t0
+    note(f"{steps} timed steps done ({elapsed / max(steps, 1) * 1e3:.0f} ms each)")
     out = {"elapsed": elapsed, "pops": pops, "evals": evals, "nbrs": nbrs, "k_ms": k_ms, "launches": k_launches,
            "kernel": trav.kernel, "table": trav.table, "state_bytes": trav.state_bytes(), "last_stats": last,
+           "last_hashes": trav.result_hashes(0, min(trav.nq, 8192)),
            "remids": float(last.n_remid.mean()), "repivots": float(last.n_repivot.mean()), "flushes": float(last.n_flush.mean())}
     trav.close()
     return out
@@ -233,7 +247,7 @@ def recall_of(idx, Q, k=10, ef=128):
     return float(np.mean([len(set(s[i]) & set(es[i])) / k for i in range(nq)]))
 
 
-def cpu_baseline(idx, queries, gpu_stats, args):
+def cpu_baseline(idx, queries, gpu_stats, args, gpu_hashes=None):
     """The oracle (C restatement of the reference control flow with a usearch-shaped index; pthreads over
     independent traversals), rebuilt -O3 -march=native for this host and timed on its cores on a bounded
     sample of the same workload: same corpus + graph (copied back from HBM), same n_to_score, fewer
@@ -257,17 +271,20 @@ def cpu_baseline(idx, queries, gpu_stats, args):
     while done < queries.shape[0]:
         q = queries[done:done + nt]
         t0 = time.perf_counter()
-        n_scored, n_pops, n_nbr = O.rad_traverse_many(g, X, q, args.n_to_score, cores)
+        n_scored, n_pops, n_nbr, hs = O.rad_traverse_many(g, X, q, args.n_to_score, cores, hashes=True)
         wall += time.perf_counter() - t0
         sl = slice(done, done + q.shape[0])
-        ok += int(((n_scored == gpu_stats.n_scored[sl]) & (n_pops == gpu_stats.n_pops[sl]) & (n_nbr == gpu_stats.n_nbr[sl])).sum())
+        same = (n_scored == gpu_stats.n_scored[sl]) & (n_pops == gpu_stats.n_pops[sl]) & (n_nbr == gpu_stats.n_nbr[sl])
+        if gpu_hashes is not None:     # the whole scored list (slots, counts, order), as one 64-bit hash per traversal
+            same &= hs == gpu_hashes[sl]
+        ok += int(same.sum())
         pops += int(n_pops.sum()); evals += int(n_scored.sum())
         done += q.shape[0]
         if wall >= args.cpu_seconds:
             break
     n1 = min(8, queries.shape[0])
     t0 = time.perf_counter()
-    s1, p1, _ = O.rad_traverse_many(g, X, queries[:n1], args.n_to_score, 1)
+    s1, p1, _ = O.rad_traverse_many(g, X, queries[:n1], args.n_to_score, 1)[:3]
     w1 = time.perf_counter() - t0
     return {"value": pops / wall, "unit": "expansions/s", "cores": cores, "kind": "port",
             "evals_per_s": evals / wall, "one_thread_value": float(p1.sum()) / w1, "cpu_model": cpu_model(),
@@ -277,86 +294,324 @@ def cpu_baseline(idx, queries, gpu_stats, args):
 
 
 # ------------------------------------------------------------------ the row-sharded leg
-def run_sharded_leg(args, idx, grp, rank, world, local_rank, barrier):
-    """BASELINE's partitioning.  Before the rows of the other ranks are dropped, the single-GPU kernel runs
-    this rank's sharded queries on the whole corpus: the sharded run must reproduce its counters exactly."""
-    from rad_amd.device import DeviceShard, DeviceTraversal, RcclComm
-    from rad_amd.sharded import RowShardedTraversal
-    n = args.n
-    nq = args.sharded_nq
-    n_batches = args.warmup + args.steps
-    qrng = np.random.default_rng(99)
-    firsts = [int(qrng.integers(0, n - world * nq)) for _ in range(n_batches)]
-    Qall = [idx.read_vectors(f, world * nq) for f in firsts]          # rank-major, identical on every rank
-    ref = DeviceTraversal(idx, Qall[-1][rank * nq:(rank + 1) * nq], args.n_to_score)
-    ref.run(0)
-    want = ref.stats()
-    ref.close()
-    rows = n // world
-    first = rank * rows
-    count = rows if rank < world - 1 else n - first
-    idx.keep_rows(first, count)
-    comm, note = None, ""
-    use_host = args.exchange != "rccl"
-    if not use_host:
-        # RCCL: rank 0 ALWAYS broadcasts an (ok, id-or-error) pair, every rank reports its init, and the
-        # whole group takes the same path; a hung init is killed by a watchdog instead of waiting forever
+def make_comms(args, grp, rank, world, local_rank, n_comms):
+    """`n_comms` RCCL communicators over all ranks (one per group of traversals).  Rank 0 ALWAYS broadcasts an
+    (ok, ids-or-error) pair, every rank reports its init, and the whole group takes the same path; a hung init is
+    killed by a watchdog instead of waiting forever.  Returns (comms or None, note, rccl-info dict or None)."""
+    from rad_amd.device import RcclComm
+    if args.exchange != "rccl":
+        return None, "", None
+    try:
+        box = (True, [RcclComm.unique_id() for _ in range(n_comms)]) if rank == 0 else None
+    except Exception as e:   # noqa: BLE001
+        box = (False, f"{type(e).__name__}: {e}")
+    ok, payload = grp.broadcast_obj(box)
+    err, comms = ("" if ok else payload), []
+    if ok:
+        dog = threading.Timer(180.0, lambda: (print(f"bench.py rank {rank}: RCCL init hung", file=sys.stderr), os._exit(3)))
+        dog.daemon = True
+        dog.start()
         try:
-            box = (True, RcclComm.unique_id()) if rank == 0 else None
+            for uid in payload:
+                comms.append(RcclComm(rank, world, uid, local_rank))
         except Exception as e:   # noqa: BLE001
-            box = (False, f"{type(e).__name__}: {e}")
-        ok, payload = grp.broadcast_obj(box)
-        err = "" if ok else payload
-        if ok:
-            dog = threading.Timer(180.0, lambda: (print(f"bench.py rank {rank}: RCCL init hung", file=sys.stderr), os._exit(3)))
-            dog.daemon = True
-            dog.start()
-            try:
-                comm = RcclComm(rank, world, payload, local_rank)
-            except Exception as e:   # noqa: BLE001
-                err = f"{type(e).__name__}: {e}"
-            dog.cancel()
-        errs = [e for e in grp.allgather_obj(err) if e]
-        if errs:
-            if comm is not None:
-                comm.close()
-            comm, use_host = None, True
-            note = " (RCCL unavailable: " + "; ".join(sorted(set(errs)))[:240] + ")"
-    res = {"steps": 0, "bytes": 0, "pops": 0, "evals": 0}
-    last = None
+            err = f"{type(e).__name__}: {e}"
+        dog.cancel()
+    errs = [e for e in grp.allgather_obj(err) if e]
+    if errs:
+        for c in comms:
+            c.close()
+        return None, " (RCCL unavailable: " + "; ".join(sorted(set(errs)))[:240] + ")", None
+    # what RCCL itself says the communicator spans: the N > 1 line carries it (VERDICT r02 #6)
+    infos = grp.allgather_obj(comms[0].info())
+    rccl = {"version": infos[0]["rccl_version"], "comm_count": infos[0]["comm_count"],
+            "comm_counts_agree": len({i["comm_count"] for i in infos}) == 1,
+            "comm_ranks": [i["comm_rank"] for i in infos], "rank_devices": [i["pci_bus_id"] for i in infos],
+            "distinct_devices": len({i["pci_bus_id"] for i in infos}), "communicators_per_rank": n_comms}
+    return comms, "", rccl
 
-    sh = DeviceShard(idx, rank, world, first, count, Qall[0], args.n_to_score)
+
+def bcast_array(grp, a, piece=1 << 27):
+    """rank 0's array on every rank over the TCP group, in pieces (host-staged rehearsals only: the product path
+    broadcasts the graph device to device, radhip_index_broadcast_graph)."""
+    meta = grp.broadcast_obj((a.shape, a.dtype.str) if grp.rank == 0 else None)
+    flat = np.ascontiguousarray(a).reshape(-1).view(np.uint8) if grp.rank == 0 else np.empty(int(np.prod(meta[0])) * np.dtype(meta[1]).itemsize, np.uint8)
+    for f in range(0, flat.shape[0], piece):
+        blob = grp.broadcast_obj(flat[f:f + piece].tobytes() if grp.rank == 0 else None)
+        if grp.rank != 0:
+            flat[f:f + piece] = np.frombuffer(blob, np.uint8)
+    return flat.view(np.dtype(meta[1])).reshape(meta[0])
+
+
+def synth_queries(args, device, firsts, count, mode):
+    """query rows [f, f + count) of the closed-form corpus, from a scratch index that holds nothing else"""
+    from rad_amd.device import DeviceIndex
+    mini = DeviceIndex(args.ndim, args.connectivity, 2 * args.connectivity, args.expansion_add, device=device)
+    out = []
+    for f in firsts:
+        mini.synth_vectors(count, seed=20260101, mode=mode, first_row=f, n_total=args.n)
+        out.append(mini.read_vectors(0, count))
+    mini.close()
+    return out
+
+
+def reference_sample(args, full, Qall_last, world, nq, ns, nfull):
+    """The single-GPU kernel on an index that holds the WHOLE corpus, for the first `ns` traversals of every rank's
+    last batch: counters of all of them, full scored lists of the first `nfull` per rank."""
+    from rad_amd.device import DeviceTraversal
+    Q = np.concatenate([Qall_last[r * nq:r * nq + ns] for r in range(world)])
+    ref = DeviceTraversal(full, Q, args.n_to_score)
+    ref.run(0)
+    st = ref.stats()
+    lists = {(r, i): ref.results(r * ns + i) for r in range(world) for i in range(nfull)}
+    ref.close()
+    return {"scored": st.n_scored.reshape(world, ns), "pops": st.n_pops.reshape(world, ns), "nbr": st.n_nbr.reshape(world, ns), "lists": lists}
+
+
+def drive_shards(args, grp, rank, world, idx, first, count, Qall, comms, barrier, ref, ns, nfull):
+    """`steps` timed batches of the row-sharded traversal on an index that holds rows [first, first + count) and the
+    whole graph.  One group of traversals, or two on two streams (--sharded-groups 2, RCCL only)."""
+    from rad_amd.device import DeviceShard
+    from rad_amd.sharded import RowShardedTraversal
+    nq = args.sharded_nq
+    use_host = comms is None
+    G = 1 if use_host else len(comms)
+    nqg = nq // G
+
+    def group_queries(Q, g):
+        return np.concatenate([Q[r * nq + g * nqg:r * nq + (g + 1) * nqg] for r in range(world)])
+
+    shards = [DeviceShard(idx, rank, world, first, count, group_queries(Qall[0], g), args.n_to_score, own_stream=g > 0) for g in range(G)]
+    res = {"steps": 0, "bytes": 0, "pops": 0, "evals": 0, "spec_asked": 0, "spec_used": 0, "spec_hits": 0}
+    last = None
 
     def one(b):
         nonlocal last
-        sh.reset(Qall[b])
+        for g, sh in enumerate(shards):
+            sh.reset(group_queries(Qall[b], g))
         if use_host:
-            drv = RowShardedTraversal(sh, grp.allgather_u32, grp.reduce_scatter_sum_u32, rank, world)
-            steps, xb = drv.run(), 0
+            drv = RowShardedTraversal(shards[0], grp.allgather_u32, grp.reduce_scatter_sum_u32, rank, world)
+            steps = drv.run()
             xb = drv.exchanged_bytes
         else:
-            steps = sh.run(comm)
-            xb = sh.timing()[3]
-        st = sh.stats()
-        last = st
-        return steps, xb, int(st.n_pops.sum()), int(st.n_scored.sum())
+            steps = shards[0].run(comms[0]) if G == 1 else shards[0].run_pair(comms[0], shards[1], comms[1])
+            xb = sum(sh.timing()[3] for sh in shards)
+        sts = [sh.stats() for sh in shards]
+        last = sts[0]
+        sp = [sh.speculation() for sh in shards]
+        return (steps, xb, sum(int(st.n_pops.sum()) for st in sts), sum(int(st.n_scored.sum()) for st in sts),
+                sum(x[1] for x in sp), sum(x[2] for x in sp), sum(x[3] for x in sp))
 
     for w in range(args.warmup):
         one(w)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        steps, xb, p, e = one(args.warmup + s)
+        steps, xb, p, e, sa, su, shh = one(args.warmup + s)
         res["steps"] += steps; res["bytes"] += xb; res["pops"] += p; res["evals"] += e
+        res["spec_asked"] += sa; res["spec_used"] += su; res["spec_hits"] += shh
     barrier()
     res["elapsed"] = time.perf_counter() - t0
-    good = int(((last.n_scored == want.n_scored) & (last.n_pops == want.n_pops) & (last.n_nbr == want.n_nbr)).sum())
-    res["parity_ok"], res["parity_n"] = good, nq
-    sh.close()
-    res["exchange"] = ("host-staged buffers over the TCP group" if use_host else "RCCL ncclAllGather + ncclReduceScatter on device buffers") + note
-    if comm is not None:
-        comm.close()
+    res["spec_depth"] = shards[0].speculation()[0]
+    res["width"] = shards[0].width
+    res["engine"] = shards[0].engine
+    res["groups"] = G
+    res["state_bytes"] = sum(sh.state_bytes() for sh in shards)
+    # parity gate: the first ns traversals of this rank (they ride in group 0) against the single-GPU kernel on the
+    # whole corpus — all three counters, and the complete scored lists (slots and both counts) of the first nfull
+    good = tot = 0
+    if ref is not None:
+        k = min(ns, nqg)
+        good = int(((last.n_scored[:k] == ref["scored"][rank][:k]) & (last.n_pops[:k] == ref["pops"][rank][:k]) & (last.n_nbr[:k] == ref["nbr"][rank][:k])).sum())
+        tot = k
+        for i in range(min(nfull, k)):
+            got, want = shards[0].results(i), ref["lists"][(rank, i)]
+            tot += 1
+            good += int(all(np.array_equal(x, y) for x, y in zip(got, want)))
+    res["parity_ok"], res["parity_n"] = good, tot
+    for sh in shards:
+        sh.close()
     return res
+
+
+def run_sharded_leg(args, idx, grp, rank, world, local_rank, barrier):
+    """BASELINE's partitioning after the replicas leg: every rank still holds the whole corpus (that IS the replicas
+    mode), so each rank computes the parity reference for its own traversals, then drops the other ranks' rows."""
+    n, nq = args.n, args.sharded_nq
+    n_batches = args.warmup + args.steps
+    qrng = np.random.default_rng(99)
+    firsts = [int(qrng.integers(0, n - world * nq)) for _ in range(n_batches)]
+    Qall = [idx.read_vectors(f, world * nq) for f in firsts]          # rank-major, identical on every rank
+    ns, nfull = min(256, nq // max(args.sharded_groups, 1)), 2
+    mine = reference_sample(args, idx, np.concatenate([Qall[-1][rank * nq:rank * nq + ns]] * 1), 1, ns, ns, nfull)
+    ref = {"scored": {rank: mine["scored"][0]}, "pops": {rank: mine["pops"][0]}, "nbr": {rank: mine["nbr"][0]},
+           "lists": {(rank, i): mine["lists"][(0, i)] for i in range(nfull)}}
+    rows = n // world
+    first = rank * rows
+    count = rows if rank < world - 1 else n - first
+    idx.keep_rows(first, count)
+    comms, note, rccl = make_comms(args, grp, rank, world, local_rank, max(args.sharded_groups, 1))
+    res = drive_shards(args, grp, rank, world, idx, first, count, Qall, comms, barrier, ref, ns, nfull)
+    res["exchange"] = ("host-staged buffers over the TCP group" if comms is None else "RCCL ncclAllGather + ncclReduceScatter on device buffers") + note
+    res["rccl"] = rccl
+    res["index_bytes"] = int(idx.info().device_bytes)
+    res["setup"] = "after the replicas leg: every rank held the whole corpus, computed its own parity reference, then kept its rows (radhip_index_keep_rows)"
+    for c in comms or []:
+        c.close()
+    return res
+
+
+def run_sharded_native(args, grp, rank, world, local_rank, barrier):
+    """--mode sharded: the shard-native setup (config[3]).  Every rank generates ONLY its rows; the graph is the
+    closed-form one (every rank generates it, no row is read) or is built once on rank 0 and broadcast device to
+    device; the parity reference is one sequential phase on rank 0 before it creates its shard, when the corpus fits."""
+    from rad_amd.device import DeviceIndex
+    n, nq, mode, M = args.n, args.sharded_nq, args.corpus_mode, args.connectivity
+    rows = n // world
+    first = rank * rows
+    count = rows if rank < world - 1 else n - first
+    n_batches = args.warmup + args.steps
+    qrng = np.random.default_rng(99)
+    firsts = [int(qrng.integers(0, n - world * nq)) for _ in range(n_batches)]
+    Qall = synth_queries(args, local_rank, firsts, world * nq, mode)
+    comms, note, rccl = make_comms(args, grp, rank, world, local_rank, max(args.sharded_groups, 1))
+    synthetic = args.graph == "synthetic" and mode == 1
+    row_stride = 16 * (1 << max(0, int(np.ceil(np.log2(max(1, (args.ndim + 127) // 128))))))
+    graph_bytes = n * (2 * M * 4 + 5) + (n // max(M - 1, 1)) * M * 4
+    fits = n * row_stride + graph_bytes < 215e9
+    want_ref = args.sharded_reference == "rank0" or (args.sharded_reference == "auto" and fits)
+    ns, nfull = min(64, nq // max(args.sharded_groups, 1)), 2
+    ref, idx, t_build, peak_full = None, None, 0.0, 0
+    if rank == 0 and (want_ref or not synthetic):
+        full = DeviceIndex(args.ndim, M, 2 * M, args.expansion_add, device=local_rank)
+        full.synth_vectors(n, seed=20260101, mode=mode)
+        if synthetic:
+            full.synth_graph(seed=777)
+        else:
+            t_build = time.perf_counter()
+            full.link_resident(seed=777, max_batch=16384)      # rows already resident: no host copy of the corpus
+            t_build = time.perf_counter() - t_build
+        peak_full = int(full.info().device_bytes)
+        if want_ref:
+            ref = reference_sample(args, full, Qall[-1], world, nq, ns, nfull)
+        if synthetic:
+            full.close()
+        else:
+            full.keep_rows(first, count)
+            idx = full
+    ref = grp.broadcast_obj(ref)
+    if idx is None:
+        idx = DeviceIndex(args.ndim, M, 2 * M, args.expansion_add, device=local_rank)
+        idx.synth_vectors_shard(count, first, n, seed=20260101, mode=mode)
+        if synthetic:
+            idx.synth_graph(seed=777)
+    if not synthetic and world > 1:
+        if comms is not None:
+            idx.broadcast_graph(comms[0], 0)                    # RCCL broadcast of the device arrays over xGMI
+        else:
+            g = idx.read_graph() if rank == 0 else (None,) * 4
+            inf0 = grp.broadcast_obj((int(idx.info().max_level), int(idx.info().entry)) if rank == 0 else None)
+            arrs = [bcast_array(grp, a) for a in g]
+            if rank != 0:
+                idx.load_graph(arrs[0], arrs[1], arrs[2], arrs[3], inf0[0], inf0[1])
+    res = drive_shards(args, grp, rank, world, idx, first, count, Qall, comms, barrier, ref, ns, nfull)
+    res["exchange"] = ("host-staged buffers over the TCP group" if comms is None else "RCCL ncclAllGather + ncclReduceScatter on device buffers") + note
+    res["rccl"] = rccl
+    res["index_bytes"] = int(idx.info().device_bytes)
+    res["t_build"] = t_build
+    res["recall"] = None
+    res["peak_full_bytes_rank0"] = peak_full
+    res["setup"] = ("shard-native: every rank generated only its rows (radhip_index_synth_vectors_shard); graph = " +
+                    ("closed form on every rank (no row is read)" if synthetic else
+                     f"built once on rank 0 from rows resident there ({t_build:.0f} s), broadcast " + ("device to device (RCCL)" if comms is not None else "over the TCP group")) +
+                    ("; parity reference: rank 0 held the whole corpus for one sequential phase before creating its shard" if want_ref else "; no parity reference (the corpus does not fit one GPU, or --sharded-reference none)"))
+    idx.close()
+    for c in comms or []:
+        c.close()
+    return res
+
+
+def sharded_report(args, grp, sh, n, world):
+    """sums over the ranks of one sharded leg -> the dict the JSON line carries"""
+    tot = grp.allreduce([sh["pops"], sh["evals"], sh["parity_ok"], sh["parity_n"], sh["spec_asked"], sh["spec_used"], sh["spec_hits"]], "sum")
+    el = float(grp.allreduce([sh["elapsed"]], "max")[0])
+    idxb = grp.allgather_obj(sh["index_bytes"])
+    rep = {
+        "value": float(tot[0]) / el, "unit": "expansions/s", "ms_per_step": el / args.steps * 1e3,
+        "evals_per_s": float(tot[1]) / el, "traversals_per_gpu_per_step": args.sharded_nq, "groups_per_gpu": sh["groups"],
+        "frontier_steps_per_step": sh["steps"] / max(args.steps, 1),
+        "exchanged_bytes_per_rank_per_step": sh["bytes"] / max(args.steps, 1),
+        "request_slots_per_traversal_per_step": sh["width"], "engine": sh["engine"],
+        "speculation": {"depth": sh["spec_depth"], "scores_requested": int(tot[4]), "scores_used": int(tot[5]),
+                        "expansions_finished_from_them": int(tot[6]),
+                        "wasted_evaluations": int(tot[4] - tot[5]),
+                        "wasted_fraction_of_all_evaluations": float(tot[4] - tot[5]) / max(float(tot[1] + tot[4] - tot[5]), 1.0)},
+        "parity_vs_single_gpu": f"{int(tot[2])}/{int(tot[3])}" if tot[3] else None, "exchange": sh["exchange"], "rccl": sh["rccl"],
+        "setup": sh["setup"], "index_bytes_per_rank": [int(b) for b in idxb], "state_bytes_per_rank": sh["state_bytes"],
+        "partitioning": f"one HNSW graph over all {n} rows (adjacency replicated), rows sharded by contiguous slot range "
+                        f"({n // world} per GPU), traversals partitioned over the ranks; per frontier step an all-gather of "
+                        f"the candidate slots and a reduce-scatter of their (and, or) scores; strict best-first, results "
+                        f"bit-identical to one GPU",
+    }
+    return rep, int(tot[2]), int(tot[3])
+
+
+# ------------------------------------------------------------------ --mode sharded: no rank holds the corpus
+def main_sharded(args, grp, rank, world, local_rank, barrier):
+    n = args.n
+    box = {}
+
+    def _leg():
+        try:
+            box["res"] = run_sharded_native(args, grp, rank, world, local_rank, barrier)
+        except BaseException as e:   # noqa: BLE001 - reported, never silent
+            box["err"] = f"{type(e).__name__}: {e}"
+    th = threading.Thread(target=_leg, daemon=True)
+    th.start()
+    th.join(args.sharded_timeout)
+    if th.is_alive() or "err" in box:
+        why = box.get("err", f"no result after {args.sharded_timeout:.0f} s (hung collective?)")
+        print(f"bench.py rank {rank}: the sharded leg failed ({why}); --mode sharded has no other value to print", file=sys.stderr)
+        os._exit(4)      # (never a re-exec: this process has touched the GPU)
+    sh = box["res"]
+    sharded, p_ok, p_n = sharded_report(args, grp, sh, n, world)
+    if p_ok != p_n:
+        raise SystemExit(f"bench.py: the sharded traversals differ from the single-GPU ones ({sharded['parity_vs_single_gpu']}): no value printed")
+    if rank != 0:
+        grp.barrier()
+        grp.close()
+        return
+    B = 16 * (1 << max(0, int(np.ceil(np.log2(max(1, (args.ndim + 127) // 128))))))
+    tot_pops = sharded["value"] * sharded["ms_per_step"] * 1e-3 * args.steps
+    tot_evals = sharded["evals_per_s"] * sharded["ms_per_step"] * 1e-3 * args.steps
+    alg = (tot_evals * (B + 4) + tot_pops * 4) / max(args.steps, 1) / world
+    ach = alg / (sharded["ms_per_step"] * 1e-3) / 1e9
+    graph_desc = "closed-form synthetic graph" if (args.graph == "synthetic" and args.corpus_mode == 1) else \
+        f"HNSW graph built on rank 0's GPU (expansion_add={args.expansion_add}, {sh['t_build']:.0f} s) and broadcast"
+    corpus_desc = {0: "dense random corpus", 1: "two-level clustered sparse corpus (round 1)",
+                   2: "hierarchical sparse corpus (neighbourhood structure at every scale)"}[args.corpus_mode]
+    out = {
+        "metric": METRIC, "value": sharded["value"], "unit": "expansions/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": sharded["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64 popcount (integer)", "data": "synthetic",
+        "config": {
+            "workload": f"{n // 1_000_000}M x {args.ndim}-bit fingerprints SHARDED over {world} GPU(s) ({n // world} rows each), connectivity="
+                        f"{args.connectivity} (level-0 width {2 * args.connectivity}), {args.sharded_nq} best-first RAD traversals per GPU and step to "
+                        f"n_to_score={args.n_to_score}, synthetic {corpus_desc}, {graph_desc}",
+            "rows": n, "ndim": args.ndim, "connectivity": args.connectivity, "nq_per_gpu": args.sharded_nq, "n_to_score": args.n_to_score,
+            "corpus_mode": args.corpus_mode,
+            "parallelism": "row-sharded (--mode sharded): " + sharded["partitioning"] + "; exchange = " + sharded["exchange"]},
+        "evals_per_s": sharded["evals_per_s"], "evals_per_expansion": sharded["evals_per_s"] / max(sharded["value"], 1.0),
+        "roofline": {"bound": "hbm", "kernel": "shard_step_kernel + shard_eval_kernel (one frontier step)", "achieved": ach, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
+                     "avg_launch_ms": sharded["ms_per_step"],
+                     "note": "a batch of the row-sharded mode is ~10^4 frontier steps, each a step kernel that ends with its slowest pop plus two small "
+                             "collectives: bound by latency, not by HBM; avg_launch_ms is the whole batch"},
+        "sharded": sharded,
+    }
+    print(json.dumps(out), flush=True)
+    grp.barrier()
+    grp.close()
 
 
 # ------------------------------------------------------------------ main (one rank)
@@ -384,18 +639,34 @@ def main():
     if args.table != "auto":
         os.environ["RADHIP_TABLE"] = args.table
     n = args.n
+    if args.mode == "sharded":
+        return main_sharded(args, grp, rank, world, local_rank, barrier)
     idx, t_build, lay = build_index(args, args.corpus_mode, local_rank)
     info = idx.info()
     B = info.row_stride
+    n_batches = args.warmup + args.steps
     if args.nq <= 0:
         # two resident rounds: traversals end at different times and the second round's workgroups take over
-        # the slots the early finishers leave
-        args.nq = 2 * idx.traversal_capacity()
-    n_batches = args.warmup + args.steps
+        # the slots the early finishers leave — or as many as the device has room for beside the index (the state
+        # of a traversal to n_to_score = 100k is ~5 MB; six wavefronts per SIMD hold 24576 traversals resident)
+        from rad_amd._lib import RadHipError, E_NOMEM
+        from rad_amd.device import DeviceTraversal
+        cap = idx.traversal_capacity()
+        for mult in (2.0, 1.5, 1.0):
+            args.nq = int(cap * mult)
+            try:
+                probe = DeviceTraversal(idx, idx.read_vectors(0, args.nq), args.n_to_score)
+                probe.close()
+                break
+            except RadHipError as e:
+                if e.code != E_NOMEM or mult == 1.0:
+                    raise
+        args.nq = int(grp.allreduce([args.nq], "min")[0])       # the same batch size on every rank
     # replicas / single GPU: every rank runs its OWN query batches (the queries are what is split)
     batches = query_batches(idx, n_batches, args.nq, n, 4242 + rank)
     leg = run_traversal_leg(args, idx, batches, args.steps, args.warmup, barrier)
     recall = recall_of(idx, batches[-1][:128]) if (rank == 0 and args.graph == "built") else None
+    note(f"recall@10 of the built graph: {recall}")
 
     sums = grp.allreduce([leg["pops"], leg["evals"]], "sum")
     elapsed_max = float(grp.allreduce([leg["elapsed"]], "max")[0])
@@ -424,12 +695,15 @@ def main():
     out["evals_per_expansion"] = float(sums[1]) / max(float(sums[0]), 1.0)
     out["queue_per_traversal"] = {"repivots": leg["repivots"], "remids": leg["remids"], "flushes": leg["flushes"]}
     out["roofline"] = roofline_of(leg, B)
+    out["build_id"] = _lib.build_id()
     prof = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(prof):
         try:
             with open(prof) as f:
                 pj = json.load(f)
-            if (pj.get("n") == n and pj.get("nq") == args.nq and pj.get("n_to_score") == args.n_to_score
+            # measured offline (rocprofv3 --pmc passes): only valid for the kernels it was measured on — the library's
+            # build id (a hash of its sources) must match, or the figure is dropped, not printed
+            if (pj.get("build_id") == _lib.build_id() and pj.get("n") == n and pj.get("nq") == args.nq and pj.get("n_to_score") == args.n_to_score
                     and pj.get("corpus_mode", 1) == args.corpus_mode and pj.get("table") == leg["table"]):
                 tr = pj.get("hbm_bytes_per_launch")
                 out["roofline"]["traffic"] = tr
@@ -464,22 +738,10 @@ def main():
                 print(json.dumps(out), flush=True)
             os._exit(0 if args.mode == "replicas" else 4)
         sh = box["res"]
-        tot = grp.allreduce([sh["pops"], sh["evals"], sh["parity_ok"], sh["parity_n"]], "sum")
-        el = float(grp.allreduce([sh["elapsed"]], "max")[0])
-        sharded = {
-            "value": float(tot[0]) / el, "unit": "expansions/s", "ms_per_step": el / args.steps * 1e3,
-            "evals_per_s": float(tot[1]) / el, "traversals_per_gpu_per_step": args.sharded_nq,
-            "frontier_steps_per_step": sh["steps"] / max(args.steps, 1),
-            "exchanged_bytes_per_rank_per_step": sh["bytes"] / max(args.steps, 1),
-            "parity_vs_single_gpu": f"{int(tot[2])}/{int(tot[3])}", "exchange": sh["exchange"],
-            "partitioning": f"one HNSW graph over all {n} rows (adjacency replicated), rows sharded by contiguous slot range "
-                            f"({n // world} per GPU), traversals partitioned over the ranks; per frontier step an all-gather of "
-                            f"the candidate slots and a reduce-scatter of their (and, or) scores; strict best-first, results "
-                            f"bit-identical to one GPU",
-        }
+        sharded, p_ok, p_n = sharded_report(args, grp, sh, n, world)
         replicas = {"value": value_replicas, "unit": "expansions/s", "ms_per_step": out["ms_per_step"],
                     "partitioning": "every GPU holds the whole corpus and graph, the query batch is split, no collective"}
-        if int(tot[2]) != int(tot[3]):
+        if p_ok != p_n:
             raise SystemExit(f"bench.py: the sharded traversals differ from the single-GPU ones ({sharded['parity_vs_single_gpu']}): no value printed")
         if args.mode == "sharded":
             out["value"], out["ms_per_step"] = sharded["value"], sharded["ms_per_step"]
@@ -499,9 +761,12 @@ def main():
 
     if world == 1:
         if not args.no_cpu_baseline:
-            cb, sample, ok = cpu_baseline(idx, batches[-1], leg["last_stats"], args)
+            note("cpu_baseline: copying corpus and graph to the host")
+            cb, sample, ok = cpu_baseline(idx, batches[-1][:8192], leg["last_stats"], args, leg["last_hashes"])
+            note(f"cpu_baseline done, parity sample {sample}")
             out["cpu_baseline"] = cb
             out["parity_sample"] = sample
+            out["parity_sample_what"] = "oracle vs GPU per traversal: scored / expansions / neighbours counters AND a 64-bit order-sensitive hash of the whole scored list (slots, and, or)"
             if not ok:
                 raise SystemExit(f"bench.py: GPU and oracle disagree on the parity sample ({sample}): no value printed")
         if args.corpus_mode != 1 and not args.no_reference_corpus and args.graph == "built":

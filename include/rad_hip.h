@@ -53,6 +53,8 @@ enum {
 const char *radhip_last_error(void);
 const char *radhip_backend_name(void); /* "hip:gfx950" */
 int radhip_abi_version(void);
+/* 16 hex digits: a hash of every source file the library was built from (kernels included) */
+const char *radhip_build_id(void);
 int radhip_device_count(int *out_count);
 
 /* ---- index: corpus + layered adjacency resident in HBM ----------------- */
@@ -246,6 +248,7 @@ typedef struct {
                             3 parked at an intermediate target,
                             negative RADHIP_E_* on a device-side failure       */
     int32_t n_remid;     /* queue maintenance: mid-level refills (the only pass over every far run) */
+    uint64_t n_upper;    /* (node, level >= 1) pairs in the upper-level visited set (what its size is chosen for) */
 } radhip_trav_stats_t;
 
 #define RADHIP_TRAV_LOG_POPS 1u  /* keep the (node, level) expansion log      */
@@ -265,6 +268,10 @@ int radhip_traversal_stats(const radhip_traversal_t *t, radhip_trav_stats_t *out
 int radhip_traversal_results(const radhip_traversal_t *t, uint32_t q, uint32_t *out_slots,
                              uint32_t *out_and, uint32_t *out_or, uint64_t cap,
                              uint64_t *out_n);
+/* order-sensitive 64-bit hash of the scored lists of traversals [first, first+count), formed on the device:
+ * sum over positions i of mix64((i << 32 | slot_i) + mix64(and_i | or_i << 16)), mix64 = the splitmix64 finaliser —
+ * a whole-list parity check that moves 8 bytes per traversal to the host (rad/scored.py:63-85 order) */
+int radhip_traversal_result_hashes(const radhip_traversal_t *t, uint32_t first, uint32_t count, uint64_t *out);
 int radhip_traversal_pop_log(const radhip_traversal_t *t, uint32_t q, uint32_t *out_nodes,
                              uint8_t *out_levels, uint64_t cap, uint64_t *out_n);
 /* device time of the traversal kernel launches since create/reset, measured
@@ -339,7 +346,7 @@ int radhip_shard_run_pair(radhip_shard_t *a, radhip_comm_t *comm_a, radhip_shard
  * rank drain its stream, abort its communicator (ncclCommAbort: the peers' collectives fail or their next look
  * times out after RADHIP_SHARD_TIMEOUT_S, default 300) and return the error; the communicator is unusable afterwards. */
 /* speculation of the thread engine (RADHIP_SHARD_SPEC = 0 | 1 | 2 queue heads expanded speculatively per step, default
- * 2): scores asked for speculatively, how many of them finished an expansion without another step, how many
+ * 0: measured on one GPU it halves the frontier steps and makes each step as much longer, profiles/r03): scores asked for speculatively, how many of them finished an expansion without another step, how many
  * expansions that were.  Committed state never depends on it (strict pop order). */
 int radhip_shard_speculation(const radhip_shard_t *s, uint32_t *out_depth, uint64_t *out_requested, uint64_t *out_used,
                              uint64_t *out_hits);

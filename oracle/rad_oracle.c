@@ -495,7 +495,24 @@ typedef struct {
     orc_trav_stats_t *stats;
     volatile uint32_t *next;
     int rc;
+    uint64_t *hashes;   /* optional: order-sensitive hash of every traversal's scored list */
 } many_ctx_t;
+
+/* order-sensitive 64-bit hash of a scored list (position, slot, and | or << 16): a wrap-around sum of mixed terms,
+ * so it can be formed in any order — the product computes the same value on the device
+ * (radhip_traversal_result_hashes) and bench.py compares the two for its parity sample */
+static uint64_t hash_mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+uint64_t orc_result_hash(const uint32_t *slots, const uint32_t *and_cnt, const uint32_t *or_cnt, uint64_t n) {
+    uint64_t h = 0;
+    for (uint64_t i = 0; i < n; ++i)
+        h += hash_mix64(((i << 32) | (uint64_t)slots[i]) + hash_mix64((uint64_t)(and_cnt[i] | (or_cnt[i] << 16))));
+    return h;
+}
 
 static void *many_worker(void *p) {
     many_ctx_t *c = (many_ctx_t *)p;
@@ -510,6 +527,7 @@ static void *many_worker(void *p) {
                                   c->n_to_score, 0, s, a, o, cap, NULL, NULL, 0,
                                   &c->stats[q]);
         if (rc) c->rc = rc;
+        if (c->hashes) c->hashes[q] = orc_result_hash(s, a, o, c->stats[q].n_scored < cap ? c->stats[q].n_scored : cap);
     }
     free(s); free(a); free(o);
     return NULL;
@@ -519,13 +537,20 @@ int orc_rad_traverse_many(const orc_graph_t *g, const uint8_t *corpus,
                           size_t row_bytes, const uint8_t *queries, uint32_t nq,
                           uint64_t n_to_score, int n_threads,
                           orc_trav_stats_t *stats_out) {
+    return orc_rad_traverse_many_h(g, corpus, row_bytes, queries, nq, n_to_score, n_threads, stats_out, NULL);
+}
+
+int orc_rad_traverse_many_h(const orc_graph_t *g, const uint8_t *corpus,
+                            size_t row_bytes, const uint8_t *queries, uint32_t nq,
+                            uint64_t n_to_score, int n_threads,
+                            orc_trav_stats_t *stats_out, uint64_t *hashes_out) {
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
     volatile uint32_t next = 0;
     many_ctx_t ctx[256];
     pthread_t th[256];
     for (int t = 0; t < n_threads; ++t) {
-        many_ctx_t c = {g, corpus, row_bytes, queries, nq, n_to_score, stats_out, &next, 0};
+        many_ctx_t c = {g, corpus, row_bytes, queries, nq, n_to_score, stats_out, &next, 0, hashes_out};
         ctx[t] = c;
         pthread_create(&th[t], NULL, many_worker, &ctx[t]);
     }

@@ -103,6 +103,12 @@ int orc_rad_traverse_many(const orc_graph_t *g, const uint8_t *corpus,
                           size_t row_bytes, const uint8_t *queries, uint32_t nq,
                           uint64_t n_to_score, int n_threads,
                           orc_trav_stats_t *stats_out /* [nq] */);
+/* the same, also returning orc_result_hash of every traversal's scored list (hashes_out[nq], may be NULL) */
+int orc_rad_traverse_many_h(const orc_graph_t *g, const uint8_t *corpus,
+                            size_t row_bytes, const uint8_t *queries, uint32_t nq,
+                            uint64_t n_to_score, int n_threads,
+                            orc_trav_stats_t *stats_out, uint64_t *hashes_out);
+uint64_t orc_result_hash(const uint32_t *slots, const uint32_t *and_cnt, const uint32_t *or_cnt, uint64_t n);
 
 /* ---- the same traversal cut at the fingerprint read (row-sharded multi-GPU mode) ----
  * The control flow of orc_rad_traverse as a stepper that never touches the corpus: one call applies the

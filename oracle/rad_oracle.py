@@ -216,20 +216,32 @@ def rad_traverse(graph: Graph, corpus: np.ndarray, query: np.ndarray, n_to_score
 
 
 def rad_traverse_many(graph: Graph, corpus: np.ndarray, queries: np.ndarray, n_to_score: int,
-                      n_threads: int):
-    """Stats only (cpu_baseline leg): returns (n_scored, n_pops, n_nbr) arrays."""
+                      n_threads: int, hashes: bool = False):
+    """Stats only (cpu_baseline leg): returns (n_scored, n_pops, n_nbr) arrays — and, with hashes=True, the
+    order-sensitive 64-bit hash of every traversal's scored list (orc_result_hash)."""
     corpus = np.ascontiguousarray(corpus, np.uint8)
     queries = np.ascontiguousarray(queries, np.uint8)
     nq = queries.shape[0]
     st = (_Stats * nq)()
     g = graph.c_struct()
-    rc = lib().orc_rad_traverse_many(C.byref(g), _p(corpus), C.c_size_t(corpus.shape[1]),
-                                     _p(queries), C.c_uint32(nq), C.c_uint64(n_to_score),
-                                     C.c_int(n_threads), st)
+    hs = np.zeros(nq, np.uint64)
+    L = lib()
+    L.orc_rad_traverse_many_h.restype = C.c_int
+    rc = L.orc_rad_traverse_many_h(C.byref(g), _p(corpus), C.c_size_t(corpus.shape[1]),
+                                   _p(queries), C.c_uint32(nq), C.c_uint64(n_to_score),
+                                   C.c_int(n_threads), st, _p(hs) if hashes else None)
     if rc:
         raise RuntimeError(f"orc_rad_traverse_many failed rc={rc}")
-    return (np.array([x.n_scored for x in st]), np.array([x.n_pops for x in st]),
-            np.array([x.n_nbr for x in st]))
+    out = (np.array([x.n_scored for x in st]), np.array([x.n_pops for x in st]),
+           np.array([x.n_nbr for x in st]))
+    return out + (hs,) if hashes else out
+
+
+def result_hash(slots, and_cnt, or_cnt) -> int:
+    s = np.ascontiguousarray(slots, np.uint32); a = np.ascontiguousarray(and_cnt, np.uint32); o = np.ascontiguousarray(or_cnt, np.uint32)
+    L = lib()
+    L.orc_result_hash.restype = C.c_uint64
+    return int(L.orc_result_hash(_p(s), _p(a), _p(o), C.c_uint64(s.shape[0])))
 
 
 class Stepper:

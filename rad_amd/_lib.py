@@ -49,7 +49,7 @@ class LayoutInfo(C.Structure):
 class TravStats(C.Structure):
     _fields_ = [("n_scored", C.c_uint64), ("n_pops", C.c_uint64), ("n_nbr", C.c_uint64),
                 ("n_repivot", C.c_uint64), ("n_flush", C.c_uint64),
-                ("status", C.c_int32), ("n_remid", C.c_int32)]
+                ("status", C.c_int32), ("n_remid", C.c_int32), ("n_upper", C.c_uint64)]
 
 
 _P = C.c_void_p
@@ -60,6 +60,7 @@ SIGNATURES = {
     "radhip_last_error": (C.c_char_p, []),
     "radhip_backend_name": (C.c_char_p, []),
     "radhip_abi_version": (C.c_int, []),
+    "radhip_build_id": (C.c_char_p, []),
     "radhip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "radhip_index_create": (C.c_int, [_U32, _U32, _U32, _U32, C.c_int, C.POINTER(_P)]),
     "radhip_index_destroy": (C.c_int, [_P]),
@@ -103,6 +104,7 @@ SIGNATURES = {
     "radhip_traversal_stats": (C.c_int, [_P, _P]),
     "radhip_traversal_results": (C.c_int, [_P, _U32, _P, _P, _P, _U64, C.POINTER(_U64)]),
     "radhip_traversal_pop_log": (C.c_int, [_P, _U32, _P, _P, _U64, C.POINTER(_U64)]),
+    "radhip_traversal_result_hashes": (C.c_int, [_P, _U32, _U32, _P]),
     "radhip_traversal_kernel_time": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_U64)]),
     "radhip_traversal_resident_capacity": (C.c_int, [_P, C.POINTER(_U32)]),
     "radhip_traversal_state_bytes": (_U64, [_P]),
@@ -166,6 +168,10 @@ def lib() -> C.CDLL:
 def check(rc: int) -> None:
     if rc != 0:
         raise RadHipError(rc, lib().radhip_last_error().decode("utf-8", "replace"))
+
+
+def build_id() -> str:
+    return lib().radhip_build_id().decode("ascii", "replace")
 
 
 def device_count() -> int:

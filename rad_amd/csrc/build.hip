@@ -597,7 +597,8 @@ static int add_impl(radhip_index *idx, const uint8_t *rows, uint64_t count, uint
             hipError_t e = hipMalloc((void **)&nfp, ncap * idx->row_stride);
             if (e != hipSuccess && ncap > need) { ncap = need; e = hipMalloc((void **)&nfp, ncap * idx->row_stride); }   // tight on memory: exact size
             if (e != hipSuccess) { rollback(); RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP, "hipMalloc for %llu rows failed: %s", (unsigned long long)need, hipGetErrorString(e)); }
-            if (idx->d_fp && first && hipMemcpy(nfp, idx->d_fp, first * idx->row_stride, hipMemcpyDeviceToDevice) != hipSuccess) {
+            if (idx->d_fp && first && (hipMemcpyAsync(nfp, idx->d_fp, first * idx->row_stride, hipMemcpyDeviceToDevice, idx->stream) != hipSuccess ||
+                                       hipStreamSynchronize(idx->stream) != hipSuccess)) {
                 (void)hipFree(nfp); rollback(); RH_FAIL(RADHIP_E_HIP, "device copy of the corpus failed");
             }
             if (idx->d_fp) { (void)hipFree(idx->d_fp); idx->device_bytes -= std::min<uint64_t>(idx->device_bytes, have * idx->row_stride); }
@@ -615,7 +616,8 @@ static int add_impl(radhip_index *idx, const uint8_t *rows, uint64_t count, uint
                 const uint64_t c = std::min<uint64_t>(piece, count - f);
                 for (uint64_t i = 0; i < c; ++i)
                     memcpy(stage.data() + i * idx->row_stride, rows + (f + i) * idx->row_bytes, idx->row_bytes);
-                if (hipMemcpy((uint8_t *)idx->d_fp + (first + f) * idx->row_stride, stage.data(), (size_t)c * idx->row_stride, hipMemcpyHostToDevice) != hipSuccess) { rollback(); RH_FAIL(RADHIP_E_HIP, "upload of the new rows failed"); }
+                if (hipMemcpyAsync((uint8_t *)idx->d_fp + (first + f) * idx->row_stride, stage.data(), (size_t)c * idx->row_stride, hipMemcpyHostToDevice, idx->stream) != hipSuccess ||
+                    hipStreamSynchronize(idx->stream) != hipSuccess) { rollback(); RH_FAIL(RADHIP_E_HIP, "upload of the new rows failed"); }
             }
         }
     }
@@ -635,10 +637,15 @@ static int add_impl(radhip_index *idx, const uint8_t *rows, uint64_t count, uint
         }
         if (rc != RADHIP_OK) { rollback(); return rc; }
     }
-    if (hipMemcpy(idx->d_levels + first, hl.data() + first, count, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(idx->d_upper_row + first, hu.data() + first, count * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(idx->d_adj0 + first * idx->cap0, 0xFF, count * idx->cap0 * 4) != hipSuccess ||
-        (nu > old_nu && hipMemset(idx->d_adjU + old_nu * idx->M, 0xFF, (nu - old_nu) * idx->M * 4) != hipSuccess)) {
+    // On the stream the build kernels run on, and waited for: hipMemset of device memory returns before the fill has run,
+    // and the library's stream is non-blocking — it does not wait for the null stream.  The first insert kernels of a
+    // 100M-row call started while the 6.4 GB fill of the adjacency was still in flight and read whatever the memory held
+    // before (zero pages in a fresh process, another index's rows in a used one: a memory fault; profiles/r03).
+    if (hipMemcpyAsync(idx->d_levels + first, hl.data() + first, count, hipMemcpyHostToDevice, idx->stream) != hipSuccess ||
+        hipMemcpyAsync(idx->d_upper_row + first, hu.data() + first, count * 4, hipMemcpyHostToDevice, idx->stream) != hipSuccess ||
+        hipMemsetAsync(idx->d_adj0 + first * idx->cap0, 0xFF, count * idx->cap0 * 4, idx->stream) != hipSuccess ||
+        (nu > old_nu && hipMemsetAsync(idx->d_adjU + old_nu * idx->M, 0xFF, (nu - old_nu) * idx->M * 4, idx->stream) != hipSuccess) ||
+        hipStreamSynchronize(idx->stream) != hipSuccess) {
         rollback();
         RH_FAIL(RADHIP_E_HIP, "initialising the new graph rows failed");
     }

@@ -163,6 +163,7 @@ int rh_ensure_device(radhip_index *idx) {
         idx->dev_ready = true;
     }
     RH_HIP(hipSetDevice(idx->device));
+    const bool uploaded = idx->h_rows_pending || (idx->has_graph && !idx->d_graph_valid);
     if (idx->h_rows_pending) {
         if (idx->d_fp) { dev_free(idx, idx->d_fp, idx->fp_cap_rows * idx->row_stride); idx->d_fp = nullptr; }
         RH_TRY(dev_alloc(idx, (void **)&idx->d_fp, idx->n * idx->row_stride));
@@ -182,6 +183,8 @@ int rh_ensure_device(radhip_index *idx) {
         RH_TRY(rh_upload_top(idx));
         idx->d_graph_valid = true;
     }
+    // (the uploads above went through the null stream; the library's stream is non-blocking: order them explicitly)
+    if (uploaded) RH_HIP(hipDeviceSynchronize());
     return RADHIP_OK;
 }
 
@@ -368,7 +371,9 @@ extern "C" int radhip_index_keep_rows(radhip_index_t *idx, uint64_t first, uint6
     const uint8_t *src = (const uint8_t *)idx->d_fp + first * idx->row_stride;
     uint4 *nfp = nullptr;
     if (hipMalloc((void **)&nfp, bytes) == hipSuccess) {
-        if (hipMemcpy(nfp, src, bytes, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(nfp); RH_FAIL(RADHIP_E_HIP, "device copy of the shard failed"); }
+        if (hipMemcpyAsync(nfp, src, bytes, hipMemcpyDeviceToDevice, idx->stream) != hipSuccess || hipStreamSynchronize(idx->stream) != hipSuccess) {
+            (void)hipFree(nfp); RH_FAIL(RADHIP_E_HIP, "device copy of the shard failed");
+        }
         dev_free(idx, idx->d_fp, idx->fp_cap_rows * idx->row_stride);
     } else {
         // no room for the shard beside the whole corpus: the shard leaves through host memory and the corpus is

@@ -174,6 +174,10 @@ __global__ void pair_rows_kernel(const uint32_t *__restrict__ adj, const uint32_
 // upload lid and build the {slot, lid} pair rows the grouped-table kernels read
 static int layout_upload(radhip_index *idx) {
     RH_TRY(rh_ensure_device(idx));
+    // Traversal objects bound to the grouped table hold d_lid / d_adjx0 / d_adjxU / d_topx: replacing an installed
+    // layout invalidates them like any other change of the index (their run() / reset() return RADHIP_E_STATE instead
+    // of reading freed arrays).  The FIRST layout of a graph frees nothing, so nobody is invalidated for it.
+    if (idx->d_lid) idx->graph_gen++;
     free_layout_dev(idx);
     const uint64_t n = idx->g_n;
     auto al = [&](void **p, size_t bytes) -> int {

@@ -66,8 +66,8 @@ struct ShardParams {
     uint64_t n_to_score;
     ShardHeader *hdr;
     unsigned long long *heap; uint64_t heap_cap;
-    unsigned long long *vis; uint32_t vlog2;      // ((slot << 4) | level) + 1
-    unsigned long long *sc; uint32_t slog2;       // (slot + 1) | packed counts << 32
+    unsigned long long *vis; uint32_t vlog2;      // visited on levels >= 1: ((slot << 4) | level) + 1
+    unsigned long long *sc; uint32_t slog2;       // scored set: (slot + 1) | (and | or << 12 | v0 << 24) << 32; v0 = visited on level 0
     uint2 *scored; uint64_t scored_cap;
     uint32_t *req;               // [nq * Wt + 16]: candidate slots of this step, then the live count
     const uint32_t *scores_in;   // [nq * Wt]: and | or << 16 of the previous step's candidates
@@ -77,6 +77,11 @@ struct ShardParams {
 // the live word behind a rank's candidates: live traversals in bits 0..30, bit 31 = a traversal of this rank
 // failed on the device (every rank sees it in the all-gather and the loop ends everywhere at the same step)
 #define SH_POISON 0x80000000u
+// The scored set (rad/scored.py) also carries the level-0 half of the visited set (rad/visited.py:17-29), as the
+// single-GPU kernel's table does: a node is visited on level 0 only after it was scored, so presence + one bit answers
+// both questions with ONE probe per level-0 neighbour; the separate visited set only holds (node, level >= 1) pairs.
+#define SH_V0 (1u << 24)
+__device__ __forceinline__ uint32_t sh_pack(uint32_t wire) { return (wire & 0xFFFFu) | ((wire >> 16) << 12); }   // and | or << 16 -> and | or << 12
 
 __device__ __forceinline__ uint64_t sh_h64(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
                 if (taken) e = sc[bi];
             }
             while (e != SH_EMPTY64) { bi = (bi + 1) & smask; e = sc[bi]; }
-            sc[bi] = (unsigned long long)(slot + 1u) | ((unsigned long long)v << 32);
+            sc[bi] = (unsigned long long)(slot + 1u) | ((unsigned long long)(sh_pack(v) | (level == 0u ? SH_V0 : 0u)) << 32);
             ins[j] = bi;
             sh_heap_push(heap, H.heap_n, rh_make_key_dev(rh_q24_dev(v & 0xFFFFu, v >> 16), slot, level));
         }
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
         // ---- prime (rad/traverser.py:141-170): Wt top-level nodes per step; distinct, nothing scored yet
         while (H.prime_at < P.n_top && k < P.Wt) {
             const uint32_t slot = P.top[H.prime_at++];
-            (void)sh_vis_tas(vis, P.vlog2, slot, (uint32_t)P.start_level, H.n_vis);
+            if (P.start_level > 0) (void)sh_vis_tas(vis, P.vlog2, slot, (uint32_t)P.start_level, H.n_vis);   // (level 0: the commit sets v0)
             req[k++] = slot;
         }
         H.pend_level = (uint32_t)P.start_level;
@@ -283,10 +288,12 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
                 for (uint32_t j = 0; j < 16; ++j) {
                     ev[j] = 0ull; es[j] = 0ull; hv[j] = 0; hs[j] = 0; ins[j] = ~0ull;
                     if (j < cnt16) {
-                        hv[j] = sh_h64((((unsigned long long)nbv[j] << 4) | level) + 1ull) & vmask;
                         hs[j] = sh_h64((uint64_t)nbv[j] + 1ull) & smask;
-                        ev[j] = vis[hv[j]];
                         es[j] = sc[hs[j]];
+                        if (level > 0u) {
+                            hv[j] = sh_h64((((unsigned long long)nbv[j] << 4) | level) + 1ull) & vmask;
+                            ev[j] = vis[hv[j]];
+                        }
                     }
                 }
 #pragma unroll
@@ -294,23 +301,25 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
                     if (j >= cnt16 || H.status != 0) continue;
                     const uint32_t nb = nbv[j];
                     H.n_nbr++;
-                    const unsigned long long k1 = (((unsigned long long)nb << 4) | level) + 1ull;
-                    uint64_t i = hv[j];
-                    unsigned long long e = ev[j];
-                    if (e == SH_EMPTY64) {
-                        bool taken = false;
+                    if (level > 0u) {   // visited test-and-set on an upper level: the small set
+                        const unsigned long long k1 = (((unsigned long long)nb << 4) | level) + 1ull;
+                        uint64_t i = hv[j];
+                        unsigned long long e = ev[j];
+                        if (e == SH_EMPTY64) {
+                            bool taken = false;
 #pragma unroll
-                        for (uint32_t t = 0; t < 16; ++t) taken = taken || (t < j && ins[t] == i);
-                        if (taken) e = vis[i];
+                            for (uint32_t t = 0; t < 16; ++t) taken = taken || (t < j && ins[t] == i);
+                            if (taken) e = vis[i];
+                        }
+                        bool seen = false;
+                        for (;;) {
+                            if (e == SH_EMPTY64) { vis[i] = k1; ins[j] = i; H.n_vis++; break; }
+                            if (e == k1) { seen = true; break; }
+                            i = (i + 1) & vmask;
+                            e = vis[i];
+                        }
+                        if (seen) continue;
                     }
-                    bool seen = false;
-                    for (;;) {
-                        if (e == SH_EMPTY64) { vis[i] = k1; ins[j] = i; H.n_vis++; break; }
-                        if (e == k1) { seen = true; break; }
-                        i = (i + 1) & vmask;
-                        e = vis[i];
-                    }
-                    if (seen) continue;
                     uint64_t si = hs[j];
                     unsigned long long se = es[j];
                     bool found = false;
@@ -322,9 +331,13 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
                         se = sc[si];
                     }
                     if (found) {
+                        if (level == 0u) {   // scored before: visited on level 0 iff its v0 bit is set
+                            if (v & SH_V0) continue;
+                            sc[si] = se | ((unsigned long long)SH_V0 << 32);
+                        }
                         if (H.heap_n >= P.heap_cap) { H.status = RADHIP_E_CAPACITY; continue; }
-                        sh_heap_push(heap, H.heap_n, rh_make_key_dev(rh_q24_dev(v & 0xFFFFu, v >> 16), nb, level));
-                    } else req[k++] = nb;
+                        sh_heap_push(heap, H.heap_n, rh_make_key_dev(rh_q24_dev(v & 0xFFFu, (v >> 12) & 0xFFFu), nb, level));
+                    } else req[k++] = nb;   // new: scored at the next step (the commit marks it visited on level 0)
                 }
             }
             // ---- every unscored neighbour among the speculative candidates of the last step?  Then their scores are
@@ -358,7 +371,22 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
             H.pend_level = level;
             if (H.status == 0 && level > 0) {
                 const uint32_t nl = level - 1u;
-                if (!sh_vis_tas(vis, P.vlog2, slot, nl, H.n_vis)) {
+                bool fresh;
+                if (nl > 0u) fresh = !sh_vis_tas(vis, P.vlog2, slot, nl, H.n_vis);
+                else {   // the node is scored, hence in the scored set: visited(node, 0) is its v0 bit
+                    fresh = false;
+                    uint64_t si = sh_h64((uint64_t)slot + 1ull) & smask;
+                    for (uint64_t tries = 0; tries <= smask; ++tries) {
+                        const unsigned long long se = sc[si];
+                        if (se == SH_EMPTY64) break;   // (unreachable by construction)
+                        if ((uint32_t)se == slot + 1u) {
+                            if (!((uint32_t)(se >> 32) & SH_V0)) { sc[si] = se | ((unsigned long long)SH_V0 << 32); fresh = true; }
+                            break;
+                        }
+                        si = (si + 1) & smask;
+                    }
+                }
+                if (fresh) {
                     if (H.heap_n >= P.heap_cap) H.status = RADHIP_E_CAPACITY;
                     else sh_heap_push(heap, H.heap_n, rh_make_key_dev((uint32_t)(key >> 38), slot, nl));
                 }
@@ -567,9 +595,9 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     s->idx = idx; s->rank = rank; s->world = world; s->nq = nq; s->n_to_score = std::min<uint64_t>(n_to_score, idx->g_n);
     s->first = row_first; s->count = row_count; s->graph_gen = idx->graph_gen;
     // request slots per traversal and step: the widest adjacency row (what one expansion can need) plus as much again
-    // for every queue head that is expanded speculatively (RADHIP_SHARD_SPEC = 0, 1 or 2; thread engine only)
+    // for every queue head that is expanded speculatively (RADHIP_SHARD_SPEC = 0 (default), 1 or 2; thread engine only)
     const uint32_t Wrow = std::max<uint32_t>(idx->cap0, idx->M);
-    uint32_t spec = wave ? 0u : 2u;
+    uint32_t spec = 0u;   // off by default: it halves the frontier steps but makes each step longer by as much (profiles/r03)
     if (const char *e = getenv("RADHIP_SHARD_SPEC")) { const int v = atoi(e); if (v >= 0 && v <= 2 && !wave) spec = (uint32_t)v; }
     const uint32_t W = Wrow * (1u + spec);
     s->W = W; s->Wrow = Wrow; s->spec = spec;
@@ -578,10 +606,14 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     const uint64_t up_pairs = idx->n_upper_rows + n_top * (uint64_t)(idx->max_level + 1);
     // queue entries = scored nodes (one level-0 entry each) + visits above level 0: the traversal kernels' estimate
     // (scored_cap * 8 / connectivity) with a factor of two on top, never more than the graph has
-    uint64_t heap_cap = scored_cap + std::min<uint64_t>(up_pairs, scored_cap * 16 / idx->M + 4096) + 64;
+    // queue entries = scored nodes (one level-0 entry each) + visits above level 0 (measured at most 0.11 x n_to_score on
+    // the bench graphs, connectivity 8: sized for 2 / connectivity of the scored nodes, never more than the graph has; a
+    // traversal that outgrows it fails with RADHIP_E_CAPACITY on every rank at the same step)
+    const uint64_t up_est = std::min<uint64_t>(up_pairs, scored_cap * 2 / idx->M + 4096);
+    uint64_t heap_cap = scored_cap + up_est + 64;
     // (test hook: a queue that is too small, so that a traversal fails on the device in the middle of a run)
     if (const char *e = getenv("RADHIP_SHARD_TEST_HEAP_CAP")) { const long long v = atoll(e); if (v > 0) heap_cap = (uint64_t)v; }
-    const uint32_t vlog2 = std::max<uint32_t>(8, sh_log2_ceil(heap_cap + heap_cap / 2));
+    const uint32_t vlog2 = std::max<uint32_t>(8, sh_log2_ceil(up_est + up_est / 2 + 64));   // (node, level >= 1) pairs only
     const uint32_t slog2 = std::max<uint32_t>(8, sh_log2_ceil(2 * scored_cap));
     ShardParams &P = s->P;
     P.adj0 = idx->d_adj0; P.upper_row = idx->d_upper_row; P.adjU = idx->d_adjU; P.top = idx->d_top;
@@ -967,6 +999,7 @@ extern "C" int radhip_shard_stats(const radhip_shard_t *s, radhip_trav_stats_t *
     for (uint32_t i = 0; i < s->nq; ++i) {
         out[i].n_scored = hdr[i].n_scored; out[i].n_pops = hdr[i].n_pops; out[i].n_nbr = hdr[i].n_nbr;
         out[i].n_repivot = 0; out[i].n_flush = 0; out[i].status = hdr[i].status; out[i].n_remid = 0;
+        out[i].n_upper = hdr[i].n_vis;
     }
     return RADHIP_OK;
 }

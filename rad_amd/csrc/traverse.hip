@@ -842,7 +842,10 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
     const uint64_t scored_cap = (n_to_score + 64 + n_top + 15) & ~(uint64_t)15;
     const uint32_t ht_log2 = std::max<uint32_t>(10, log2_ceil(2 * scored_cap));
     const uint64_t up_pairs = idx->n_upper_rows + n_top * (uint64_t)(idx->max_level + 1);
-    uint64_t ut_need = std::min<uint64_t>(2 * up_pairs + 64, scored_cap * 8 / idx->M + 1024);
+    // (node, level >= 1) visits of a traversal: measured at most 0.11 x n_to_score on the bench graphs (mean 0.035,
+    // connectivity 8; profiles/r03) — the set is sized for 2 / connectivity of the scored nodes at 3/4 load, and the key
+    // pool (every live queue key) with it; a traversal that outgrows them re-runs with four times the room (trav_grow_upper)
+    uint64_t ut_need = std::min<uint64_t>(2 * up_pairs + 64, scored_cap * 2 / idx->M + 4096);
     const uint32_t ut_log2 = std::max<uint32_t>(10, log2_ceil(ut_need));
     if (ht_log2 > 31 || ut_log2 > 31) { delete t; RH_FAIL(RADHIP_E_INVALID, "n_to_score too large"); }
     // every live queue key fits: a scored node is in the queue once per level at most; trav4_kernel collects
@@ -983,8 +986,8 @@ static int trav_launch(radhip_traversal *t) {
     radhip_index *idx = t->idx;
 #ifdef RH_PROFILE
     static unsigned long long *d_prof = nullptr;
-    if (!d_prof) { (void)hipMalloc((void **)&d_prof, 208); }
-    (void)hipMemset(d_prof, 0, 208);
+    if (!d_prof) { (void)hipMalloc((void **)&d_prof, 256); }
+    (void)hipMemset(d_prof, 0, 256);
     t->P.prof = d_prof;
 #else
     t->P.prof = nullptr;
@@ -1018,13 +1021,15 @@ static int trav_launch(radhip_traversal *t) {
     RH_HIP(hipEventElapsedTime(&ms, t->ev0, t->ev1));
 #ifdef RH_PROFILE
     {
-        unsigned long long hp[26];
-        (void)hipMemcpy(hp, t->P.prof, 208, hipMemcpyDeviceToHost);
+        unsigned long long hp[32];
+        (void)hipMemcpy(hp, t->P.prof, 256, hipMemcpyDeviceToHost);
         unsigned long long tot = 0; for (int i = 0; i < 9; ++i) tot += hp[i];
         const char *nm[10] = {"loophead", "flush", "pop", "decode+adj", "probe", "eval", "finish+enqueue", "old+descent-pre", "repivot", ""};
         fprintf(stderr, "[prof] total %llu cycles:", tot);
         for (int i = 0; i < 9; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * hp[i] / (tot ? tot : 1));
         fprintf(stderr, "; %llu re-pivot events of a wavefront, %.0f cycles each\n", hp[9], hp[9] ? (double)hp[8] / hp[9] : 0.0);
+        fprintf(stderr, "[prof] %llu wavefront rounds, %.0f cycles each; probe stages %llu with %.2f dependent round trips and %.1f lanes each\n",
+                hp[30], hp[30] ? (double)tot / hp[30] : 0.0, hp[26], hp[26] ? (double)hp[27] / hp[26] : 0.0, hp[26] ? (double)hp[31] / hp[26] : 0.0);
         {   // inside the re-pivot (these sections are part of "repivot" above, whose own slot holds what is left)
             const char *n2[8] = {"lo-scan", "remid", "pivot-choice", "stg-scan", "squeeze", "mid-loop", "extract-tail", "dry+tail"};
             unsigned long long t2 = hp[8]; for (int i = 10; i < 18; ++i) t2 += hp[i];
@@ -1048,21 +1053,23 @@ static int trav_launch(radhip_traversal *t) {
 // only for an adversarial layout).  The batch has not returned anything yet: re-arm it with the per-slot
 // hash table, which has no such limit below its sized capacity, and run it again from the start.
 static int trav_fall_back_to_hash(radhip_traversal *t) {
-    radhip_index *idx = t->idx;
+    // allocate first, release the grouped table only when the per-slot table exists
+    const size_t ht_bytes = ((size_t)t->nq << t->ht_log2) * 8;
+    unsigned long long *n_ht = nullptr;
+    hipError_t e = hipMalloc((void **)&n_ht, ht_bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP,
+                                 "hipMalloc(%zu) for the hash-table fallback failed: %s", ht_bytes, hipGetErrorString(e)); }
     if (t->P.gt) { (void)hipFree(t->P.gt); t->P.gt = nullptr; t->state_bytes -= t->gt_bytes; t->gt_bytes = 0; }
     t->use_gt = false;
+    t->P.ht = n_ht;
     t->P.ht_log2 = t->ht_log2;
-    t->ht_bytes = ((size_t)t->nq << t->ht_log2) * 8;
-    hipError_t e = hipMalloc((void **)&t->P.ht, t->ht_bytes);
-    if (e != hipSuccess) RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP,
-                                 "hipMalloc(%zu) for the hash-table fallback failed: %s", t->ht_bytes, hipGetErrorString(e));
+    t->ht_bytes = ht_bytes;
     t->state_bytes += t->ht_bytes;
     t->fresh_tables = true;
     const double ms = t->kernel_ms;
     const uint64_t launches = t->launches;
     RH_TRY(trav_upload_queries(t, t->h_queries.data()));
     t->kernel_ms = ms; t->launches = launches;   // the aborted launch stays on the clock
-    (void)idx;
     return RADHIP_OK;
 }
 
@@ -1073,29 +1080,53 @@ static int trav_fall_back_to_hash(radhip_traversal *t) {
 static int trav_grow_upper(radhip_traversal *t) {
     if (t->P.ut_log2 + 2 > 31) RH_FAIL(RADHIP_E_CAPACITY, "the upper-level visited set cannot grow any further");
     TravParams &P = t->P;
-    (void)hipFree(P.ut); P.ut = nullptr; t->state_bytes -= t->ut_bytes;
-    (void)hipFree(P.pq); P.pq = nullptr; t->state_bytes -= t->pq_bytes;
-    P.ut_log2 += 2;
-    P.pq_cap = P.scored_cap + ((uint64_t)1 << P.ut_log2);
-    if (P.pq_cap >= 0xFFFFFFFFull) RH_FAIL(RADHIP_E_CAPACITY, "the key pool cannot grow any further");
-    t->ut_bytes = ((size_t)t->nq << P.ut_log2) * 8;
-    t->pq_bytes = (size_t)t->nq * P.pq_cap * 8;
-    hipError_t e = hipMalloc((void **)&P.ut, t->ut_bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&P.pq, t->pq_bytes);
+    // allocate first, swap on success: a failed regrow (four times the room is where memory runs out) leaves the
+    // object exactly as it was — still bound to valid buffers, its batch still failed with RADHIP_E_CAPACITY
+    const uint32_t ut_log2 = P.ut_log2 + 2;
+    const uint64_t pq_cap = P.scored_cap + ((uint64_t)1 << ut_log2);
+    if (pq_cap >= 0xFFFFFFFFull) RH_FAIL(RADHIP_E_CAPACITY, "the key pool cannot grow any further");
+    const size_t ut_bytes = ((size_t)t->nq << ut_log2) * 8, pq_bytes = (size_t)t->nq * pq_cap * 8;
+    unsigned long long *n_ut = nullptr, *n_pq = nullptr;
+    uint32_t *n_pl = nullptr;
+    uint8_t *n_plv = nullptr;
+    hipError_t e = hipMalloc((void **)&n_ut, ut_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&n_pq, pq_bytes);
     if (e == hipSuccess && P.poplog_nodes) {
-        (void)hipFree(P.poplog_nodes); (void)hipFree(P.poplog_levels);
-        P.poplog_nodes = nullptr; P.poplog_levels = nullptr;
-        P.poplog_cap = P.pq_cap;
-        e = hipMalloc((void **)&P.poplog_nodes, (size_t)t->nq * P.poplog_cap * 4);
-        if (e == hipSuccess) e = hipMalloc((void **)&P.poplog_levels, (size_t)t->nq * P.poplog_cap);
+        e = hipMalloc((void **)&n_pl, (size_t)t->nq * pq_cap * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&n_plv, (size_t)t->nq * pq_cap);
     }
-    if (e != hipSuccess) RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP,
-                                 "growing the traversal state failed: %s", hipGetErrorString(e));
-    t->state_bytes += t->ut_bytes + t->pq_bytes;
+    if (e != hipSuccess) {
+        if (n_ut) (void)hipFree(n_ut);
+        if (n_pq) (void)hipFree(n_pq);
+        if (n_pl) (void)hipFree(n_pl);
+        if (n_plv) (void)hipFree(n_plv);
+        (void)hipGetLastError();
+        RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP, "growing the traversal state failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(P.ut); (void)hipFree(P.pq);
+    t->state_bytes -= t->ut_bytes + t->pq_bytes;
+    P.ut = n_ut; P.pq = n_pq; P.ut_log2 = ut_log2; P.pq_cap = pq_cap;
+    t->ut_bytes = ut_bytes; t->pq_bytes = pq_bytes;
+    t->state_bytes += ut_bytes + pq_bytes;
+    if (n_pl) {
+        (void)hipFree(P.poplog_nodes); (void)hipFree(P.poplog_levels);
+        P.poplog_nodes = n_pl; P.poplog_levels = n_plv; P.poplog_cap = pq_cap;
+    }
     t->fresh_tables = true;
     const double ms = t->kernel_ms;
     const uint64_t launches = t->launches;
+    // the re-arm starts every traversal again: the stop targets the caller had set (radhip_traversal_set_targets)
+    // are put back afterwards
+    std::vector<TravHeader> old(t->nq);
+    RH_HIP(hipMemcpy(old.data(), P.hdr, t->hdr_bytes, hipMemcpyDeviceToHost));
     RH_TRY(trav_upload_queries(t, t->h_queries.data()));
+    {
+        std::vector<TravHeader> hdr(t->nq);
+        RH_HIP(hipMemcpy(hdr.data(), P.hdr, t->hdr_bytes, hipMemcpyDeviceToHost));
+        bool any = false;
+        for (uint32_t i = 0; i < t->nq; ++i) if (old[i].target != hdr[i].target) { hdr[i].target = old[i].target; any = true; }
+        if (any) RH_HIP(hipMemcpy(P.hdr, hdr.data(), t->hdr_bytes, hipMemcpyHostToDevice));
+    }
     t->kernel_ms = ms; t->launches = launches;
     return RADHIP_OK;
 }
@@ -1143,6 +1174,7 @@ extern "C" int radhip_traversal_stats(const radhip_traversal_t *t, radhip_trav_s
         out[i].n_scored = hdr[i].n_scored; out[i].n_pops = hdr[i].n_pops; out[i].n_nbr = hdr[i].n_nbr;
         out[i].n_repivot = hdr[i].n_repivot; out[i].n_flush = hdr[i].n_flush;
         out[i].status = hdr[i].status; out[i].n_remid = (int32_t)hdr[i].n_remid;
+        out[i].n_upper = hdr[i].n_upper;
     }
     return RADHIP_OK;
 }
@@ -1166,6 +1198,50 @@ extern "C" int radhip_traversal_results(const radhip_traversal_t *t, uint32_t q,
         if (out_or) out_or[i] = buf[i].y >> 16;
     }
     return RADHIP_OK;
+}
+
+// ---- order-sensitive 64-bit hash of every traversal's scored list, formed on the device (a wrap-around sum of mixed
+// (position, slot, and | or << 16) terms: any summation order gives the same value).  bench.py compares it with the
+// oracle's orc_result_hash for its parity sample: the whole scored list, not three counters.
+__device__ __forceinline__ unsigned long long th_mix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void result_hash_kernel(const uint2 *scored, uint64_t scored_cap, const TravHeader *hdr, uint32_t first_q,
+                                                          unsigned long long *out) {
+    const uint32_t q = first_q + blockIdx.x;
+    const uint64_t n = hdr[q].n_scored < scored_cap ? hdr[q].n_scored : scored_cap;
+    const uint2 *sc = scored + (uint64_t)q * scored_cap;
+    unsigned long long h = 0;
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint2 e = sc[i];
+        h += th_mix64(((unsigned long long)i << 32 | (unsigned long long)e.x) + th_mix64((unsigned long long)e.y));
+    }
+    for (int o = 32; o > 0; o >>= 1) h += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(h >> 32), o) << 32 | (uint32_t)__shfl_xor((int)(uint32_t)h, o));
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&out[blockIdx.x], h);
+}
+
+extern "C" int radhip_traversal_result_hashes(const radhip_traversal_t *t, uint32_t first, uint32_t count, uint64_t *out) {
+    if (!t || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if ((uint64_t)first + count > t->nq) RH_FAIL(RADHIP_E_RANGE, "traversals [%u, %u) out of range", first, first + count);
+    if (count == 0) return RADHIP_OK;
+    radhip_index *idx = t->idx;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_HIP(hipSetDevice(idx->device));
+    unsigned long long *d = nullptr;
+    RH_HIP(hipMalloc((void **)&d, (size_t)count * 8));
+    int rc = RADHIP_OK;
+    if (hipMemsetAsync(d, 0, (size_t)count * 8, idx->stream) != hipSuccess) rc = RADHIP_E_HIP;
+    if (rc == RADHIP_OK) {
+        hipLaunchKernelGGL(result_hash_kernel, dim3(count), dim3(256), 0, idx->stream, t->P.scored, t->P.scored_cap, t->P.hdr, first, d);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d, (size_t)count * 8, hipMemcpyDeviceToHost, idx->stream) != hipSuccess ||
+            hipStreamSynchronize(idx->stream) != hipSuccess) rc = RADHIP_E_HIP;
+    }
+    (void)hipFree(d);
+    if (rc != RADHIP_OK) radhip_set_error("radhip_traversal_result_hashes failed");
+    return rc;
 }
 
 extern "C" int radhip_traversal_pop_log(const radhip_traversal_t *t, uint32_t q, uint32_t *out_nodes,
@@ -1265,7 +1341,7 @@ extern "C" int radhip_debug_sort_staging(radhip_index_t *idx, const uint64_t *ke
         hipMalloc((void **)&dc, (size_t)batches * 4) != hipSuccess) rc = RADHIP_E_NOMEM;
     if (rc == RADHIP_OK && (hipMemcpy(din, keys, bytes, hipMemcpyHostToDevice) != hipSuccess ||
                             hipMemcpy(dc, counts, (size_t)batches * 4, hipMemcpyHostToDevice) != hipSuccess ||
-                            hipMemset(dout, 0, bytes) != hipSuccess)) rc = RADHIP_E_HIP;
+                            hipMemsetAsync(dout, 0, bytes, idx->stream) != hipSuccess)) rc = RADHIP_E_HIP;
     if (rc == RADHIP_OK) {
         hipLaunchKernelGGL(debug_sort_kernel, dim3(batches), dim3(64), 0, idx->stream, din, dc, dout);
         if (hipStreamSynchronize(idx->stream) != hipSuccess) rc = RADHIP_E_HIP;

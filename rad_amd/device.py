@@ -209,11 +209,12 @@ class TraversalStats:
     n_repivot: np.ndarray = None
     n_flush: np.ndarray = None
     n_remid: np.ndarray = None
+    n_upper: np.ndarray = None
 
 
 # numpy view of _lib.TravStats (include/rad_hip.h radhip_trav_stats_t)
 _TRAV_STATS_DTYPE = np.dtype([("n_scored", "<u8"), ("n_pops", "<u8"), ("n_nbr", "<u8"), ("n_repivot", "<u8"),
-                              ("n_flush", "<u8"), ("status", "<i4"), ("n_remid", "<i4")])
+                              ("n_flush", "<u8"), ("status", "<i4"), ("n_remid", "<i4"), ("n_upper", "<u8")])
 assert _TRAV_STATS_DTYPE.itemsize == C.sizeof(_lib.TravStats)
 
 
@@ -260,7 +261,8 @@ class DeviceTraversal:
         rec = np.frombuffer(arr, dtype=_TRAV_STATS_DTYPE, count=self.nq)   # one view, no per-record Python
         return TraversalStats(rec["n_scored"].astype(np.int64), rec["n_pops"].astype(np.int64),
                               rec["n_nbr"].astype(np.int64), rec["status"].astype(np.int32),
-                              rec["n_repivot"].astype(np.int64), rec["n_flush"].astype(np.int64), rec["n_remid"].astype(np.int64))
+                              rec["n_repivot"].astype(np.int64), rec["n_flush"].astype(np.int64), rec["n_remid"].astype(np.int64),
+                              rec["n_upper"].astype(np.int64))
 
     def results(self, q: int):
         """(slots, and, or) of traversal q in traversal order."""
@@ -272,6 +274,13 @@ class DeviceTraversal:
         o = np.empty(k, np.uint32)
         check(self._L.radhip_traversal_results(self._h, q, ptr(s), ptr(a), ptr(o), k, C.byref(n)))
         return s, a, o
+
+    def result_hashes(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        """order-sensitive 64-bit hash of the scored lists of traversals [first, first+count), formed on the device"""
+        count = self.nq - first if count is None else count
+        out = np.zeros(count, np.uint64)
+        check(self._L.radhip_traversal_result_hashes(self._h, first, count, ptr(out)))
+        return out
 
     def pop_log(self, q: int):
         n = C.c_uint64(0)

@@ -121,3 +121,40 @@ def test_oracle_parity_at_100m(big, oracle, monkeypatch):
     assert t1.run() == 0
     check(t1, sel)
     t1.close()
+
+
+def test_bench_workload_itself_full_results_vs_oracle(gpu, oracle, monkeypatch):
+    """The bench workload itself: 100M hierarchical rows, the HNSW graph BUILT on the GPU with the
+    bench's parameters (connectivity 8, expansion_add 64, batches of 16384, rows linked where they are resident),
+    n_to_score = 100k — 16 traversals compared with the oracle in full: expansion order, scored order, both counts;
+    plus the order-sensitive result hash the bench's parity sample uses."""
+    from rad_amd.device import DeviceIndex, DeviceTraversal
+    monkeypatch.setenv("RADHIP_TRAV", "4")
+    monkeypatch.delenv("RADHIP_TABLE", raising=False)
+    n, nts = 100_000_000, 100_000
+    idx = DeviceIndex(1024, 8, 16, 64)
+    idx.synth_vectors(n, seed=20260101, mode=2)
+    idx.link_resident(seed=777, max_batch=16384)
+    X = np.empty((n, 128), np.uint8)
+    for f in range(0, n, 10_000_000):
+        X[f:f + 10_000_000] = idx.read_vectors(f, 10_000_000)
+    levels, adj0, upper_row, adjU = idx.read_graph()
+    inf = idx.info()
+    g = oracle.Graph(n, 16, 8, int(inf.max_level), int(inf.entry), levels, adj0, upper_row, adjU)
+    rows = np.random.default_rng(77).integers(0, n, 16)
+    Q = X[rows].copy()
+    t = DeviceTraversal(idx, Q, nts, log_pops=True)
+    assert t.kernel == "trav4_kernel" and t.table == "bucket" and t.run() == 0
+    hashes = t.result_hashes()
+    st = t.stats()
+    for i in range(16):
+        want = oracle.rad_traverse(g, X, Q[i], nts)
+        s, a, o = t.results(i)
+        nodes, lv = t.pop_log(i)
+        assert np.array_equal(nodes, want.pop_nodes) and np.array_equal(lv, want.pop_levels), i
+        assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt), i
+        assert int(hashes[i]) == oracle.result_hash(want.slots, want.and_cnt, want.or_cnt), i
+        assert st.n_pops[i] == want.n_pops and st.n_nbr[i] == want.n_nbr
+    assert (st.n_remid > 0).all()
+    t.close()
+    idx.close()

@@ -41,6 +41,8 @@ def test_grouped_table_matches_oracle_and_hash_table(gpu, oracle, monkeypatch, m
     Q = X[np.random.default_rng(1).integers(0, n, 37)]     # 37: a ragged last wavefront
     monkeypatch.setenv("RADHIP_TABLE", "hash")
     _check(oracle, idx, X, g, Q, n_to_score, "hash")
+    monkeypatch.delenv("RADHIP_TABLE")
+    _check(oracle, idx, X, g, Q, n_to_score, "bucket")     # the kernel's default table
     info = idx.optimize_layout()
     assert info.valid and info.group == 384 and info.id_limit >= n
     lid = idx.read_layout()
@@ -109,3 +111,27 @@ def test_traversal_object_does_not_survive_an_add(gpu, oracle):
         t.run()
     with pytest.raises(RadHipError):
         t.reset(X[:4])
+
+
+def test_replacing_the_layout_invalidates_grouped_traversals(gpu, oracle, monkeypatch):
+    """A traversal bound to the grouped table holds the layout's device arrays: installing another layout frees
+    them, so the object must refuse to run (RADHIP_E_STATE) instead of reading freed memory."""
+    from rad_amd import _lib
+    from rad_amd._lib import RadHipError
+    from rad_amd.device import DeviceTraversal
+    monkeypatch.setenv("RADHIP_TRAV", "4")
+    idx, X, g = _index(oracle, 8000, 1024, 8, 48, 2)
+    idx.optimize_layout()
+    monkeypatch.setenv("RADHIP_TABLE", "group")
+    Q = X[:5].copy()
+    t = DeviceTraversal(idx, Q, 500)
+    assert t.table == "grouped" and t.run() == 0
+    idx.set_layout(np.random.default_rng(5).permutation(8000).astype(np.uint32))
+    for call in (lambda: t.reset(Q), lambda: t.run()):
+        with pytest.raises(RadHipError) as ei:
+            call()
+        assert ei.value.code == _lib.E_STATE
+    t2 = DeviceTraversal(idx, Q, 500)            # a new object sees the new layout
+    assert t2.table == "grouped" and t2.run() == 0
+    for i in range(5):
+        assert np.array_equal(t2.results(i)[0], oracle.rad_traverse(g, X, Q[i], 500).slots)

@@ -196,7 +196,7 @@ def test_staging_sort_network(gpu):
     cap = int(L.radhip_debug_staging_capacity())
     assert 64 <= cap <= 256
     rng = np.random.default_rng(5)
-    counts = np.array(list(range(1, cap + 1)) + [cap] * 64 + [1, 2, 3, 63, 64, 65, 127, 128, 129], np.uint32)
+    counts = np.array(list(range(1, cap + 1)) + [cap] * 64 + [min(c, cap) for c in (1, 2, 3, 63, 64, 65, 127, 128, 129)], np.uint32)
     keys = rng.integers(0, 1 << 62, (counts.size, 256), dtype=np.uint64)
     keys[5::7] >>= np.uint64(40)                                   # many equal high words: the low word decides
     keys[3::11, ::2] = keys[3::11, 1::2]                           # exact duplicates

@@ -92,3 +92,17 @@ def test_batched_build_recall_matches_sequential_build(gpu, oracle):
     seq.load_graph(g.levels, g.adj0, g.upper_row, g.adjU, g.max_level, g.entry)
     rb, rs = _recall(batched, Q), _recall(seq, Q)
     assert rb >= rs - 0.03 and rb >= 0.9, (rb, rs)
+
+
+def test_batched_build_recall_at_1m_rows(gpu, oracle):
+    """At 1M rows the 16384-batch build was measured within 0.01 of the sequential insert (0.914 vs 0.923 at ef 128,
+    profiles/r02/README.md; the sequential build takes 6 minutes of CPU, so it is not repeated here): the batched
+    build alone must stay at that level."""
+    from rad_amd.device import DeviceIndex
+    n = 1_000_000
+    idx = DeviceIndex(1024, 8, 16, 64)
+    idx.synth_vectors(n, seed=20260101, mode=2)
+    idx.link_resident(seed=777, max_batch=16384)
+    Q = np.concatenate([idx.read_vectors(int(r), 1) for r in np.random.default_rng(9).integers(0, n, 256)])
+    r = _recall(idx, Q)
+    assert r >= 0.90, r

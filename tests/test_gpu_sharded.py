@@ -143,11 +143,11 @@ def _row_sharded_setup(oracle, n, nts, world, nq, mode=2, seed=7):
     return X, g, full, Qall
 
 
-@pytest.fixture(params=["wave", "thread", "thread-spec0", "thread-spec1"])
+@pytest.fixture(params=["wave", "thread", "thread-spec1", "thread-spec2"])
 def engine(request, monkeypatch):
     """both step kernels of shard.hip: the single-GPU traversal kernel cut at the fingerprint read, and the
-    thread-per-traversal restatement of the oracle's stepper — the latter without speculation and with one or
-    two (the default) queue heads expanded speculatively per step: the committed state must not depend on it"""
+    thread-per-traversal restatement of the oracle's stepper — the latter without speculation (the default) and with
+    one or two queue heads expanded speculatively per step: the committed state must not depend on it"""
     name, _, spec = request.param.partition("-spec")
     monkeypatch.setenv("RADHIP_SHARD_ENGINE", name)
     if spec:

@@ -406,3 +406,47 @@ def test_key_map_lives_in_the_library():
     want = rng.integers(0, big_n, 1000)
     assert np.array_equal(big.get_node_ids_from_keys(bk[want]), want.astype(np.uint64))
     assert [int(x) for x in big.get_neighbors(5, 0)] == [6, int(bk[6])]
+
+
+def test_http_front_serves_the_reference_json_shapes(tmp_path):
+    """the thin HTTP front (rad_amd/hnsw_server.py) answers the routes and JSON keys the
+    reference's RemoteHNSWService client reads (rad/hnsw_server.py:505-511, 538-543, 561-568, 604-613), from an
+    index that holds only a graph — no GPU involved."""
+    from starlette.testclient import TestClient
+    from rad_amd.hnsw_server import create_app
+    from rad_amd.index import Index
+    z = load_graph_npz("g1t64_graph.npz")
+    n = z["levels"].shape[0]
+    keys = np.arange(n, dtype=np.uint64) * 7 + 1000
+    idx = Index(ndim=64, dtype="b1", metric="tanimoto", connectivity=4, expansion_add=20)
+    idx.load_graph(keys, None, z["levels"], z["adj0"], z["upper_row"], z["adjU"], int(z["max_level"]), int(z["entry"]))
+    db = str(tmp_path / "nodes.db")
+    con = sqlite3.connect(db)
+    con.execute("CREATE TABLE nodes (node_key INTEGER PRIMARY KEY, smi TEXT NOT NULL)")
+    con.executemany("INSERT INTO nodes VALUES (?, ?)", [(int(k), f"C{i}") for i, k in enumerate(keys) if i % 3])   # every third key missing
+    con.commit(); con.close()
+    c = TestClient(create_app(idx, database_path=db, api_key="s3cret"))
+    hdr = {"Authorization": "Bearer s3cret"}
+    assert c.get("/ping").json() == {"pong": True}
+    assert c.get("/neighbors/5/0").status_code == 401                       # bearer auth, as the reference's
+    r = c.get("/neighbors/5/0", headers=hdr).json()
+    row = [int(x) for x in z["adj0"][5] if x != NO_SLOT]
+    assert set(r) == {"node_id", "level", "neighbors", "neighbor_count", "request_id"}
+    assert r["node_id"] == 5 and r["level"] == 0 and r["neighbor_count"] == len(row)
+    assert r["neighbors"][0::2] == row and r["neighbors"][1::2] == [f"C{x}" if x % 3 else "" for x in row]
+    t = c.get("/top-level-nodes", headers=hdr).json()
+    tops = np.nonzero(z["levels"] == int(z["max_level"]))[0].tolist()
+    assert set(t) == {"top_nodes", "node_count", "cached", "request_id"} and t["node_count"] == len(tops) and t["top_nodes"][0::2] == tops
+    assert len(t["top_nodes"]) == 2 * t["node_count"] and all(isinstance(s, str) for s in t["top_nodes"][1::2])
+    h = c.get("/health").json()
+    assert h["status"] == "healthy" and h["hnsw_size"] == n and h["hnsw_max_level"] == int(z["max_level"])
+    i = c.get("/info", headers=hdr).json()
+    assert i["service_type"] == "RemoteHNSWService" and i["hnsw_info"]["size"] == n and i["authentication_enabled"] is True
+    assert set(i["hnsw_info"]) >= {"max_level", "size", "connectivity", "dtype", "ndim", "capacity", "memory_usage", "multi"}
+    # range errors are 400s with the reference's messages
+    assert c.get(f"/neighbors/{n + 3}/0", headers=hdr).status_code == 400
+    assert c.get(f"/neighbors/5/{int(z['max_level']) + 1}", headers=hdr).status_code == 400
+    assert c.get(f"/neighbors/5/{int(z['levels'][5]) + 1}", headers=hdr).status_code == 400 or int(z["levels"][5]) == int(z["max_level"])
+    m = c.post("/neighbors-many", headers=hdr, json={"pairs": [[5, 0], [6, 0]]}).json()
+    assert [x["neighbors"] for x in m["results"]] == [c.get("/neighbors/5/0", headers=hdr).json()["neighbors"],
+                                                      c.get("/neighbors/6/0", headers=hdr).json()["neighbors"]]

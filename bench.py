@@ -79,8 +79,8 @@ def parse_args():
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="replicas", help="which N > 1 leg `value` reports (both always run)")
     ap.add_argument("--sharded-timeout", type=float, default=420.0,
                     help="seconds the sharded leg may take before the line is printed without it (a hung collective must not cost the run)")
-    ap.add_argument("--sharded-nq", type=int, default=16384,
-                    help="traversals per rank and step of the sharded leg (a step costs 86 us at 8192, 89 us at 16384: the more the better; 6.5 MB of state each)")
+    ap.add_argument("--sharded-nq", type=int, default=32768,
+                    help="traversals per rank and step of the sharded leg (a step costs 87 us at 16384, 106 us at 32768: the more the better; 4.5 MB of state each)")
     ap.add_argument("--sharded-groups", type=int, default=1, choices=[1, 2],
                     help="groups the sharded traversals of a rank are split into: 2 = two streams and two communicators, one group's "
                          "step kernel overlaps the other's collectives (RCCL exchange only)")
@@ -402,12 +402,13 @@ def drive_shards(args, grp, rank, world, idx, first, count, Qall, comms, barrier
         return (steps, xb, sum(int(st.n_pops.sum()) for st in sts), sum(int(st.n_scored.sum()) for st in sts),
                 sum(x[1] for x in sp), sum(x[2] for x in sp), sum(x[3] for x in sp))
 
-    for w in range(args.warmup):
+    n_warm, n_steps = args.sh_warmup, args.sh_steps
+    for w in range(n_warm):
         one(w)
     barrier()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        steps, xb, p, e, sa, su, shh = one(args.warmup + s)
+    for s in range(n_steps):
+        steps, xb, p, e, sa, su, shh = one(n_warm + s)
         res["steps"] += steps; res["bytes"] += xb; res["pops"] += p; res["evals"] += e
         res["spec_asked"] += sa; res["spec_used"] += su; res["spec_hits"] += shh
     barrier()
@@ -438,7 +439,10 @@ def run_sharded_leg(args, idx, grp, rank, world, local_rank, barrier):
     """BASELINE's partitioning after the replicas leg: every rank still holds the whole corpus (that IS the replicas
     mode), so each rank computes the parity reference for its own traversals, then drops the other ranks' rows."""
     n, nq = args.n, args.sharded_nq
-    n_batches = args.warmup + args.steps
+    # the side leg of a --mode replicas run: a batch of the sharded loop is ~36000 frontier steps (4 s on one GPU, more
+    # with real collectives), so it times at most two batches behind one warm-up; `value` does not come from here
+    args.sh_warmup, args.sh_steps = min(args.warmup, 1), min(args.steps, 2)
+    n_batches = args.sh_warmup + args.sh_steps
     qrng = np.random.default_rng(99)
     firsts = [int(qrng.integers(0, n - world * nq)) for _ in range(n_batches)]
     Qall = [idx.read_vectors(f, world * nq) for f in firsts]          # rank-major, identical on every rank
@@ -470,6 +474,7 @@ def run_sharded_native(args, grp, rank, world, local_rank, barrier):
     rows = n // world
     first = rank * rows
     count = rows if rank < world - 1 else n - first
+    args.sh_warmup, args.sh_steps = args.warmup, args.steps          # --mode sharded: `value` comes from here, exactly K steps
     n_batches = args.warmup + args.steps
     qrng = np.random.default_rng(99)
     firsts = [int(qrng.integers(0, n - world * nq)) for _ in range(n_batches)]
@@ -537,10 +542,10 @@ def sharded_report(args, grp, sh, n, world):
     el = float(grp.allreduce([sh["elapsed"]], "max")[0])
     idxb = grp.allgather_obj(sh["index_bytes"])
     rep = {
-        "value": float(tot[0]) / el, "unit": "expansions/s", "ms_per_step": el / args.steps * 1e3,
+        "value": float(tot[0]) / el, "unit": "expansions/s", "ms_per_step": el / args.sh_steps * 1e3, "steps": args.sh_steps, "warmup": args.sh_warmup,
         "evals_per_s": float(tot[1]) / el, "traversals_per_gpu_per_step": args.sharded_nq, "groups_per_gpu": sh["groups"],
-        "frontier_steps_per_step": sh["steps"] / max(args.steps, 1),
-        "exchanged_bytes_per_rank_per_step": sh["bytes"] / max(args.steps, 1),
+        "frontier_steps_per_step": sh["steps"] / max(args.sh_steps, 1),
+        "exchanged_bytes_per_rank_per_step": sh["bytes"] / max(args.sh_steps, 1),
         "request_slots_per_traversal_per_step": sh["width"], "engine": sh["engine"],
         "speculation": {"depth": sh["spec_depth"], "scores_requested": int(tot[4]), "scores_used": int(tot[5]),
                         "expansions_finished_from_them": int(tot[6]),

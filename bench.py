@@ -50,6 +50,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+RANDOM_LINE_PEAK_G = 38.2   # G random 128-B line reads per second at a 64 GiB footprint, measured (profiles/r03/latency_footprint.log)
 METRIC = "neighbor-expansions/sec (1024-bit Tanimoto) + HBM GB/s vs roofline"
 
 
@@ -715,6 +716,15 @@ def main():
                 out["roofline"]["traffic_source"] = "profiles/traffic_latest.json (rocprofv3 --pmc, separate passes, measured offline)"
                 if tr:
                     out["roofline"]["hbm_real_gbs"] = tr / (out["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
+                # the second ceiling of a pointer-chasing kernel: memory-side REQUESTS per second.  An MI355X serves 38 G
+                # independent random 128-B line reads per second over footprints >= 16 GiB however many wavefronts ask
+                # (scripts/latency_footprint.hip, profiles/r03/latency_footprint.log); partial-line writes cost more.
+                rq, wq = pj.get("read_requests_128B"), (pj.get("write_requests") or {}).get("total")
+                if rq and wq:
+                    rate = (rq + wq) / (out["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
+                    out["roofline"]["memory_requests"] = {
+                        "reads_per_launch": rq, "writes_per_launch": wq, "achieved_G_per_s": rate,
+                        "device_random_line_reads_G_per_s": RANDOM_LINE_PEAK_G, "frac": rate / RANDOM_LINE_PEAK_G}
         except Exception:
             pass
 

@@ -356,10 +356,11 @@ int radhip_shard_speculation(const radhip_shard_t *s, uint32_t *out_depth, uint6
  * per traversal and step (RADHIP_NO_SLOT padded; the widest adjacency row, times 1 + the speculation depth); scores
  * are and | or << 16. */
 uint32_t radhip_shard_width(const radhip_shard_t *s);
-/* which step kernel drives the local traversals: 0 = "thread" (one thread per traversal, heap + sets in HBM; the
- * default), 1 = "wave" (the single-GPU traversal kernel cut at the fingerprint read, four traversals per
- * wavefront; RADHIP_SHARD_ENGINE=wave, adjacency rows of <= 16 slots; slower per step, kept as a cross-check).
- * Same results. */
+/* which step kernel drives the local traversals (RADHIP_SHARD_ENGINE = row | thread | wave, read at create):
+ * 2 = "row" (the default: sixteen lanes per traversal, a 16-ary heap whose levels are 128-B lines, neighbours probed
+ * one per lane; state in HBM), 0 = "thread" (one thread per traversal, 8-ary heap; also the fallback for queues of
+ * more than 2^24 entries), 1 = "wave" (the single-GPU traversal kernel cut at the fingerprint read; adjacency rows
+ * of <= 16 slots; slowest per step, kept as a cross-check).  Same results from all three. */
 int radhip_shard_engine(const radhip_shard_t *s);
 int radhip_shard_step(radhip_shard_t *s, uint32_t *out_live);
 int radhip_shard_get_requests(radhip_shard_t *s, uint32_t *host /* [nq * W] */);

@@ -65,7 +65,7 @@ struct ShardParams {
     int32_t start_level;
     uint64_t n_to_score;
     ShardHeader *hdr;
-    unsigned long long *heap; uint64_t heap_cap;
+    unsigned long long *heap; uint64_t heap_cap, heap_stride;   // heap_stride keys per traversal (a multiple of 16, >= heap_cap + 16)
     unsigned long long *vis; uint32_t vlog2;      // visited on levels >= 1: ((slot << 4) | level) + 1
     unsigned long long *sc; uint32_t slog2;       // scored set: (slot + 1) | (and | or << 12 | v0 << 24) << 32; v0 = visited on level 0
     uint2 *scored; uint64_t scored_cap;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
         if (H.status < 0) atomicOr(live, SH_POISON);
         return;
     }
-    unsigned long long *heap = P.heap + (uint64_t)q * P.heap_cap;
+    unsigned long long *heap = P.heap + (uint64_t)q * P.heap_stride;
     unsigned long long *vis = P.vis + ((uint64_t)q << P.vlog2);
     unsigned long long *sc = P.sc + ((uint64_t)q << P.slog2);
     uint2 *scored = P.scored + (uint64_t)q * P.scored_cap;
@@ -464,6 +464,326 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
     else if (H.status < 0) atomicOr(live, SH_POISON);
 }
 
+// ---- the "row" engine: the same step, sixteen lanes per traversal -------------------------------------------------
+// One thread per traversal makes every load instruction of a wavefront touch 64 traversals' state — 64 lines in 64
+// different pages — and walks a row's neighbours and a heap level's children one instruction at a time.  Here a
+// traversal is a ROW of 16 lanes (4 rows per wavefront, as in trav4_kernel): a 16-ary heap whose level is one 128-B line
+// read by the row in one request (a pop costs ~log16 n dependent reads, a push ONE: all ancestors are known in advance and
+// are loaded together), the neighbours of an adjacency row probed one per lane, set inserts by compare-and-swap (keys of
+// one expansion are distinct, so the sets end up with the same members whatever lane wins a bucket), candidates ranked by
+// ballot so that they leave in row order.  All state stays in HBM between steps, as in the thread engine — nothing to
+// save or restore — and the results are the same bit for bit: the pop order is a function of the queue's key SET only.
+// Heap node j lives at h[j + 15]: the 16 children of a node start at a multiple of 16 keys.
+#define SHR_AT(j) ((j) + 15ull)
+__device__ __forceinline__ unsigned long long shr_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void shr_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t shr_ld32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long shr_row_min(unsigned long long v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(v, o, 16); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t shr_ballot(bool p, uint32_t gshift) { return (uint32_t)(__ballot(p) >> gshift) & 0xFFFFu; }
+// every lane of the row passes the same key
+__device__ __forceinline__ void shr_push(unsigned long long *h, uint64_t &n, unsigned long long key, uint32_t gl, uint32_t gshift) {
+    const uint64_t i = n++;
+    // lane l < 6 owns ancestor l of the new leaf (16^6 > any queue this engine is created for)
+    uint64_t a = i, my = ~0ull;
+    bool valid = true;
+#pragma unroll
+    for (uint32_t t = 0; t < 6; ++t) {
+        valid = valid && a > 0;
+        a = valid ? (a - 1) >> 4 : 0;
+        if (t == gl) my = valid ? a : ~0ull;
+    }
+    // parent and grandparent first: a new key rarely rises further (the loop is request-bound: 6 lines per push were a
+    // third of a step's memory requests), the other four ancestors only when it does
+    unsigned long long av = (gl < 2u && my != ~0ull) ? shr_ld(&h[SHR_AT(my)]) : 0ull;   // (0 <= every key: ends the sift)
+    uint32_t b = shr_ballot(gl < 2u && my != ~0ull && av > key, gshift);
+    if (b == 3u) {
+        if (gl >= 2u && my != ~0ull) av = shr_ld(&h[SHR_AT(my)]);
+        b = shr_ballot(my != ~0ull && av > key, gshift);
+    }
+    const uint32_t u = (uint32_t)__builtin_ctz(~b);                               // ancestors that move down one level
+    const uint64_t below = __shfl_up(my, 1, 16);
+    if (gl < u) shr_st(&h[SHR_AT(gl == 0 ? i : below)], av);
+    if (gl == (u ? u - 1u : 0u)) shr_st(&h[SHR_AT(u ? my : i)], key);
+}
+__device__ __forceinline__ unsigned long long shr_pop(unsigned long long *h, uint64_t &n, uint32_t gl, uint32_t gshift) {
+    const unsigned long long top = shr_ld(&h[SHR_AT(0)]);
+    const unsigned long long last = shr_ld(&h[SHR_AT(n - 1)]);
+    --n;
+    if (n == 0) return top;
+    uint64_t i = 0;
+    for (;;) {
+        const uint64_t c0 = 16ull * i + 1ull;
+        if (c0 >= n) break;
+        const unsigned long long ck = c0 + gl < n ? shr_ld(&h[SHR_AT(c0 + gl)]) : RH_KEY_INF;   // one line
+        const unsigned long long mk = shr_row_min(ck);
+        if (mk >= last) break;
+        const uint32_t m = (uint32_t)__builtin_ctz(shr_ballot(ck == mk, gshift));
+        if (gl == 0) shr_st(&h[SHR_AT(i)], mk);
+        i = c0 + m;
+    }
+    if (gl == 0) shr_st(&h[SHR_AT(i)], last);
+    return top;
+}
+// true if (slot, level) was already in the set, else inserts it: ONE lane per key, distinct keys per call site
+__device__ __forceinline__ bool shr_vis_tas(unsigned long long *vis, uint64_t vmask, uint32_t slot, uint32_t level) {
+    const unsigned long long k1 = (((unsigned long long)slot << 4) | level) + 1ull;
+    uint64_t i = sh_h64(k1) & vmask;
+    for (;;) {
+        const unsigned long long old = atomicCAS(&vis[i], SH_EMPTY64, k1);
+        if (old == SH_EMPTY64) return false;
+        if (old == k1) return true;
+        i = (i + 1) & vmask;
+    }
+}
+
+struct ShardRowLds { uint32_t cand[4][16]; uint32_t sp_req[4][32]; uint32_t sp_sc[4][32]; };
+
+__global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
+    __shared__ ShardRowLds L;
+    const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15u, gshift = g * 16u;
+    const uint32_t lt = (1u << gl) - 1u;
+    const uint32_t q = blockIdx.x * 4u + g;
+    if (q >= P.nq) return;                 // (whole rows leave: everything below is row-uniform control flow)
+    ShardHeader H = P.hdr[q];
+    uint32_t *req = P.req + (uint64_t)q * P.Wt;
+    uint32_t *live = P.req + (uint64_t)P.nq * P.Wt;
+    if (H.status != 0) {
+        if (H.n_pend || H.n_spec) {
+            for (uint32_t i = gl; i < P.Wt; i += 16u) req[i] = RADHIP_NO_SLOT;
+            H.n_pend = 0; H.n_spec = 0;
+            if (gl == 0) P.hdr[q] = H;
+        }
+        if (H.status < 0 && gl == 0) atomicOr(live, SH_POISON);
+        return;
+    }
+    unsigned long long *heap = P.heap + (uint64_t)q * P.heap_stride;
+    unsigned long long *vis = P.vis + ((uint64_t)q << P.vlog2);
+    unsigned long long *sc = P.sc + ((uint64_t)q << P.slog2);
+    uint2 *scored = P.scored + (uint64_t)q * P.scored_cap;
+    const uint32_t *sin = P.scores_in + (uint64_t)q * P.Wt;
+    const uint64_t vmask = (1ull << P.vlog2) - 1ull, smask = (1ull << P.slog2) - 1ull;
+    const uint32_t vis_limit = (uint32_t)(((1ull << P.vlog2) / 4ull) * 3ull);
+
+    // ---- commit n <= 16 scored candidates (lane j holds candidate j), in order: scored list, scored set, queue
+    auto commit_row = [&](uint32_t slot, uint32_t v, uint32_t n, uint32_t level) {
+        if (H.n_scored + n > P.scored_cap || H.heap_n + n > P.heap_cap) { H.status = RADHIP_E_CAPACITY; return; }
+        const bool on = gl < n;
+        if (on) {
+            scored[H.n_scored + gl] = make_uint2(slot, v);
+            const unsigned long long e = (unsigned long long)(slot + 1u) | ((unsigned long long)(sh_pack(v) | (level == 0u ? SH_V0 : 0u)) << 32);
+            uint64_t bi = sh_h64((uint64_t)slot + 1ull) & smask;
+            while (atomicCAS(&sc[bi], SH_EMPTY64, e) != SH_EMPTY64) bi = (bi + 1) & smask;
+        }
+        H.n_scored += n;
+        const unsigned long long key = rh_make_key_dev(rh_q24_dev(v & 0xFFFFu, v >> 16), slot, level);
+        for (uint32_t j = 0; j < n; ++j) shr_push(heap, H.heap_n, __shfl(key, (int)j, 16), gl, gshift);
+    };
+
+    // ---- finish: the candidates of the last step are scored now
+    for (uint32_t base = 0; base < H.n_pend && H.status == 0; base += 16u) {
+        const bool on = base + gl < H.n_pend;
+        const uint32_t sl = on ? req[base + gl] : RADHIP_NO_SLOT, sv = on ? sin[base + gl] : 0u;
+        commit_row(sl, sv, H.n_pend - base < 16u ? H.n_pend - base : 16u, H.pend_level);
+    }
+    H.n_pend = 0;
+    const uint32_t n_cache = H.n_spec;
+    uint32_t k = 0;
+    bool primed_now = false;
+    if (H.status == 0 && H.prime_at < P.n_top) {
+        // ---- prime (rad/traverser.py:141-170): Wt top-level nodes per step
+        const uint32_t cnt = P.n_top - H.prime_at < P.Wt ? P.n_top - H.prime_at : P.Wt;
+        for (uint32_t i = gl; i < ((cnt + 15u) & ~15u); i += 16u) {
+            bool ins = false;
+            if (i < cnt) {
+                const uint32_t slot = P.top[H.prime_at + i];
+                if (P.start_level > 0) ins = !shr_vis_tas(vis, vmask, slot, (uint32_t)P.start_level);
+                req[i] = slot;
+            }
+            H.n_vis += (uint32_t)__popc(shr_ballot(ins, gshift));
+        }
+        H.prime_at += cnt; k = cnt;
+        H.pend_level = (uint32_t)P.start_level;
+        primed_now = true;
+    } else if (H.status == 0) {
+        uint32_t hits = 0;
+        for (uint32_t it = 0; it < P.max_inner + hits; ++it) {
+            if (H.n_scored >= P.n_to_score) { H.status = 1; break; }
+            if (H.heap_n == 0) { H.status = 2; break; }
+            if (H.n_vis > vis_limit) { H.status = RADHIP_E_CAPACITY; break; }
+            const unsigned long long key = shr_pop(heap, H.heap_n, gl, gshift);
+            uint32_t slot, level;
+            rh_decode_key(key, &slot, &level);
+            if (P.poplog_nodes && H.n_pops < P.poplog_cap && gl == 0) {
+                P.poplog_nodes[(uint64_t)q * P.poplog_cap + H.n_pops] = slot;
+                P.poplog_levels[(uint64_t)q * P.poplog_cap + H.n_pops] = (uint8_t)level;
+            }
+            H.n_pops++;
+            const uint32_t cap = level == 0 ? P.cap0 : P.capU;
+            const uint32_t *row = level == 0 ? P.adj0 + (uint64_t)slot * P.cap0
+                                             : P.adjU + ((uint64_t)P.upper_row[slot] + (level - 1u)) * P.capU;
+            bool row_end = false;
+            for (uint32_t base = 0; base < cap && !row_end && H.status == 0; base += 16u) {
+                const uint32_t nb = base + gl < cap ? row[base + gl] : RADHIP_NO_SLOT;
+                const uint32_t endm = shr_ballot(nb == RADHIP_NO_SLOT, gshift);
+                const uint32_t cnt16 = endm ? (uint32_t)__builtin_ctz(endm) : 16u;   // the row ends at its first empty slot
+                if (endm) row_end = true;
+                H.n_nbr += cnt16;
+                bool go = gl < cnt16;
+                if (level > 0u) {            // visited test-and-set on an upper level: the small set
+                    bool ins = false;
+                    if (go) { const bool seen = shr_vis_tas(vis, vmask, nb, level); ins = !seen; go = !seen; }
+                    H.n_vis += (uint32_t)__popc(shr_ballot(ins, gshift));
+                }
+                bool found = false;
+                uint32_t v = 0;
+                uint64_t si = 0;
+                unsigned long long se = 0ull;
+                if (go) {
+                    si = sh_h64((uint64_t)nb + 1ull) & smask;
+                    for (;;) {
+                        se = shr_ld(&sc[si]);
+                        if (se == SH_EMPTY64) break;
+                        if ((uint32_t)se == nb + 1u) { found = true; v = (uint32_t)(se >> 32); break; }
+                        si = (si + 1) & smask;
+                    }
+                }
+                const bool isnew = go && !found;
+                bool old_push = go && found;
+                if (old_push && level == 0u) {   // scored before: visited on level 0 iff its v0 bit is set
+                    if (v & SH_V0) old_push = false;
+                    else shr_st(&sc[si], se | ((unsigned long long)SH_V0 << 32));
+                }
+                const uint32_t nm = shr_ballot(isnew, gshift);
+                if (isnew) {
+                    const uint32_t at = k + (uint32_t)__popc(nm & lt);
+                    req[at] = nb;
+                    if (at < 16u) L.cand[g][at] = nb;
+                }
+                k += (uint32_t)__popc(nm);
+                uint32_t om = shr_ballot(old_push, gshift);
+                if (om) {
+                    if (H.heap_n + (uint32_t)__popc(om) > P.heap_cap) { H.status = RADHIP_E_CAPACITY; om = 0u; }
+                    const unsigned long long okey = rh_make_key_dev(rh_q24_dev(v & 0xFFFu, (v >> 12) & 0xFFFu), nb, level);
+                    while (om) {
+                        const uint32_t j = (uint32_t)__builtin_ctz(om);
+                        om &= om - 1u;
+                        shr_push(heap, H.heap_n, __shfl(okey, (int)j, 16), gl, gshift);
+                    }
+                }
+            }
+            // ---- every unscored neighbour among the speculative candidates of the last step: commit from their scores
+            if (k && H.status == 0 && n_cache && k <= 16u) {
+                int seg = -1;
+                if (H.spec_cnt[0] && H.spec_node[0] == slot && H.spec_level[0] == level) seg = 0;
+                else if (H.spec_cnt[1] && H.spec_node[1] == slot && H.spec_level[1] == level) seg = 1;
+                if (seg >= 0 && H.spec_cnt[seg] <= 32u) {
+                    const uint32_t off = P.W + H.spec_off[seg], cn = H.spec_cnt[seg];
+                    for (uint32_t j = gl; j < cn; j += 16u) { L.sp_req[g][j] = req[off + j]; L.sp_sc[g][j] = sin[off + j]; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t want = gl < k ? L.cand[g][gl] : RADHIP_NO_SLOT;
+                    uint32_t sv = 0u;
+                    bool have = false;
+                    if (gl < k) for (uint32_t j = 0; j < cn; ++j) if (L.sp_req[g][j] == want) { sv = L.sp_sc[g][j]; have = true; }
+                    const uint32_t got = (uint32_t)__popc(shr_ballot(have, gshift));
+                    __builtin_amdgcn_wave_barrier();
+                    if (got == k) {
+                        commit_row(want, sv, k, level);
+                        H.spec_hit++; H.spec_used += k;
+                        k = 0;
+                        if (hits < P.spec) hits++;
+                    }
+                }
+            }
+            H.pend_level = level;
+            if (H.status == 0 && level > 0) {
+                const uint32_t nl = level - 1u;
+                uint32_t fresh = 0u;
+                if (gl == 0) {
+                    if (nl > 0u) fresh = shr_vis_tas(vis, vmask, slot, nl) ? 0u : 1u;
+                    else {   // the node is scored, hence in the scored set: visited(node, 0) is its v0 bit
+                        uint64_t si = sh_h64((uint64_t)slot + 1ull) & smask;
+                        for (uint64_t tries = 0; tries <= smask; ++tries) {
+                            const unsigned long long se = shr_ld(&sc[si]);
+                            if (se == SH_EMPTY64) break;   // (unreachable by construction)
+                            if ((uint32_t)se == slot + 1u) {
+                                if (!((uint32_t)(se >> 32) & SH_V0)) { shr_st(&sc[si], se | ((unsigned long long)SH_V0 << 32)); fresh = 1u; }
+                                break;
+                            }
+                            si = (si + 1) & smask;
+                        }
+                    }
+                }
+                fresh = (uint32_t)__shfl((int)fresh, 0, 16);
+                if (fresh) {
+                    if (nl > 0u) H.n_vis++;
+                    if (H.heap_n >= P.heap_cap) H.status = RADHIP_E_CAPACITY;
+                    else shr_push(heap, H.heap_n, rh_make_key_dev((uint32_t)(key >> 38), slot, nl), gl, gshift);
+                }
+            }
+            if (k || H.status != 0) break;
+        }
+    }
+    for (uint32_t i = k + gl; i < P.W && i < P.Wt; i += 16u) req[i] = RADHIP_NO_SLOT;
+    H.n_pend = k;
+    // ---- speculate: the unscored neighbours of the next queue heads (the head, then the smallest of its children:
+    // the runner-up is one of them).  Read-only.
+    uint32_t ns = 0;
+    H.spec_cnt[0] = H.spec_cnt[1] = 0;
+    if (P.spec && H.status == 0 && !primed_now && H.prime_at >= P.n_top && H.heap_n > 0) {
+        for (uint32_t s = 0; s < P.spec && s < 2u; ++s) {
+            unsigned long long hk;
+            if (s == 0) hk = shr_ld(&heap[SHR_AT(0)]);
+            else hk = shr_row_min(1ull + gl < H.heap_n ? shr_ld(&heap[SHR_AT(1ull + gl)]) : RH_KEY_INF);
+            if (hk == RH_KEY_INF) break;
+            uint32_t slot, level;
+            rh_decode_key(hk, &slot, &level);
+            const uint32_t cap = level == 0 ? P.cap0 : P.capU;
+            const uint32_t *row = level == 0 ? P.adj0 + (uint64_t)slot * P.cap0
+                                             : P.adjU + ((uint64_t)P.upper_row[slot] + (level - 1u)) * P.capU;
+            const uint32_t off0 = ns;
+            bool row_end = false;
+            for (uint32_t base = 0; base < cap && !row_end; base += 16u) {
+                const uint32_t nb = base + gl < cap ? row[base + gl] : RADHIP_NO_SLOT;
+                const uint32_t endm = shr_ballot(nb == RADHIP_NO_SLOT, gshift);
+                const uint32_t cnt16 = endm ? (uint32_t)__builtin_ctz(endm) : 16u;
+                if (endm) row_end = true;
+                bool unscored = false;
+                if (gl < cnt16) {
+                    uint64_t si = sh_h64((uint64_t)nb + 1ull) & smask;
+                    unscored = true;
+                    for (;;) {
+                        const unsigned long long se = shr_ld(&sc[si]);
+                        if (se == SH_EMPTY64) break;
+                        if ((uint32_t)se == nb + 1u) { unscored = false; break; }
+                        si = (si + 1) & smask;
+                    }
+                }
+                const uint32_t um = shr_ballot(unscored, gshift);
+                const uint32_t at = P.W + ns + (uint32_t)__popc(um & lt);
+                if (unscored && at < P.Wt) req[at] = nb;
+                const uint32_t room = P.Wt - (P.W + ns);
+                ns += (uint32_t)__popc(um) < room ? (uint32_t)__popc(um) : room;
+            }
+            H.spec_node[s] = slot; H.spec_level[s] = (uint8_t)level; H.spec_off[s] = (uint8_t)off0;
+            H.spec_cnt[s] = (uint8_t)(ns - off0 > 255u ? 255u : ns - off0);
+        }
+        H.spec_req += ns;
+    }
+    if (!primed_now) { for (uint32_t i = P.W + ns + gl; i < P.Wt; i += 16u) req[i] = RADHIP_NO_SLOT; }
+    else { for (uint32_t i = (k > P.W ? k : P.W) + gl; i < P.Wt; i += 16u) req[i] = RADHIP_NO_SLOT; }
+    H.n_spec = ns;
+    if (gl == 0) {
+        P.hdr[q] = H;
+        if (H.status == 0) atomicAdd(live, 1u);   // live traversals of this rank
+        else if (H.status < 0) atomicOr(live, SH_POISON);
+    }
+}
+
 // ---- candidates of every rank x the rows this rank owns: LPR lanes per candidate, U in flight per lane
 struct EvalParams {
     const uint4 *fp;             // rows [first, first + count) of the corpus
@@ -533,7 +853,8 @@ struct radhip_shard {
     uint32_t *d_qpop = nullptr, *d_req = nullptr, *d_req_all = nullptr, *d_out = nullptr, *d_in = nullptr;
     uint64_t graph_gen = 0;
     size_t state_bytes = 0;
-    radhip_traversal *wave = nullptr;   // the wave engine's state (null: thread engine)
+    radhip_traversal *wave = nullptr;   // the wave engine's state (null: thread or row engine)
+    bool row = false;                   // the row engine (shard_step_row_kernel) instead of the thread engine
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double step_ms = 0.0, eval_ms = 0.0;
     uint64_t steps = 0, exchanged_bytes = 0;
@@ -571,9 +892,11 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
                 (unsigned long long)row_first, (unsigned long long)(row_first + row_count),
                 (unsigned long long)idx->shard_first, (unsigned long long)(idx->shard_first + idx->n));
     radhip_traversal *wave = nullptr;
+    bool want_row = false;
     {
         const char *e = getenv("RADHIP_SHARD_ENGINE");
         const bool want_wave = e && e[0] == 'w';
+        want_row = !e || e[0] == 'r';   // the default since round 3
         if (want_wave && std::max<uint32_t>(idx->cap0, idx->M) > 16)
             RH_FAIL(RADHIP_E_INVALID, "RADHIP_SHARD_ENGINE=wave needs adjacency rows of at most 16 slots");
         if (want_wave)   // (takes the index lock itself)
@@ -597,7 +920,9 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     // request slots per traversal and step: the widest adjacency row (what one expansion can need) plus as much again
     // for every queue head that is expanded speculatively (RADHIP_SHARD_SPEC = 0 (default), 1 or 2; thread engine only)
     const uint32_t Wrow = std::max<uint32_t>(idx->cap0, idx->M);
-    uint32_t spec = 0u;   // off by default: it halves the frontier steps but makes each step longer by as much (profiles/r03)
+    // thread engine: off by default (it halves the frontier steps but makes each step longer by as much); row engine: 2
+    // (0.54 x the steps — and collectives — at 1.6 x the step: profiles/r03)
+    uint32_t spec = (want_row && !wave) ? 2u : 0u;
     if (const char *e = getenv("RADHIP_SHARD_SPEC")) { const int v = atoi(e); if (v >= 0 && v <= 2 && !wave) spec = (uint32_t)v; }
     const uint32_t W = Wrow * (1u + spec);
     s->W = W; s->Wrow = Wrow; s->spec = spec;
@@ -619,7 +944,8 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     P.adj0 = idx->d_adj0; P.upper_row = idx->d_upper_row; P.adjU = idx->d_adjU; P.top = idx->d_top;
     P.n_top = idx->n_top; P.cap0 = idx->cap0; P.capU = idx->M; P.nq = nq; P.W = Wrow; P.Wt = W; P.spec = spec;
     P.start_level = idx->max_level > 0 ? idx->max_level - 1 : 0;
-    P.n_to_score = s->n_to_score; P.heap_cap = heap_cap; P.vlog2 = vlog2; P.slog2 = slog2; P.scored_cap = scored_cap;
+    s->row = want_row && !wave && heap_cap <= (1ull << 24);   // (shr_push loads six ancestors: heaps below 16^6 entries)
+    P.n_to_score = s->n_to_score; P.heap_cap = heap_cap; P.heap_stride = (heap_cap + 16 + 15) & ~15ull; P.vlog2 = vlog2; P.slog2 = slog2; P.scored_cap = scored_cap;
     // pops per step while nothing needs a score: the step ends with its slowest traversal, so a long inner loop
     // makes every step as slow as the unluckiest of thousands of traversals (measured: 2 beats 1, 4 and 8)
     P.max_inner = 2;
@@ -639,7 +965,7 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     };
     if (!wave) {
         al((void **)&P.hdr, (size_t)nq * sizeof(ShardHeader), true);
-        al((void **)&P.heap, (size_t)nq * heap_cap * 8, false);
+        al((void **)&P.heap, (size_t)nq * P.heap_stride * 8, false);
         al((void **)&P.vis, ((size_t)nq << vlog2) * 8, true);
         al((void **)&P.sc, ((size_t)nq << slog2) * 8, true);
         al((void **)&P.scored, (size_t)nq * scored_cap * sizeof(uint2), false);
@@ -736,7 +1062,7 @@ extern "C" int radhip_shard_speculation(const radhip_shard_t *s, uint32_t *out_d
     if (out_hits) *out_hits = hi;
     return RADHIP_OK;
 }
-extern "C" int radhip_shard_engine(const radhip_shard_t *s) { return s && s->wave ? 1 : 0; }
+extern "C" int radhip_shard_engine(const radhip_shard_t *s) { return !s ? 0 : s->wave ? 1 : s->row ? 2 : 0; }
 extern "C" uint64_t radhip_shard_state_bytes(const radhip_shard_t *s) { return s ? s->state_bytes : 0; }
 
 static int shard_check(radhip_shard *s) {
@@ -751,7 +1077,8 @@ static int shard_enqueue_step(radhip_shard *s, bool zero_live) {
     // (in the product loop the evaluation kernel of the step before has zeroed the live count: one launch less)
     if (zero_live) RH_HIP(hipMemsetAsync(s->d_req + (size_t)s->nq * s->W, 0, 64, s->stream));
     if (s->wave) return rh_trav_enqueue_shard_step(s->wave);
-    hipLaunchKernelGGL(shard_step_kernel, dim3((s->nq + 63u) / 64u), dim3(64), 0, s->stream, s->P);
+    if (s->row) hipLaunchKernelGGL(shard_step_row_kernel, dim3((s->nq + 3u) / 4u), dim3(64), 0, s->stream, s->P);
+    else hipLaunchKernelGGL(shard_step_kernel, dim3((s->nq + 63u) / 64u), dim3(64), 0, s->stream, s->P);
     RH_HIP(hipGetLastError());
     return RADHIP_OK;
 }

@@ -143,11 +143,12 @@ def _row_sharded_setup(oracle, n, nts, world, nq, mode=2, seed=7):
     return X, g, full, Qall
 
 
-@pytest.fixture(params=["wave", "thread", "thread-spec1", "thread-spec2"])
+@pytest.fixture(params=["row", "row-spec0", "row-spec1", "wave", "thread", "thread-spec1", "thread-spec2"])
 def engine(request, monkeypatch):
-    """both step kernels of shard.hip: the single-GPU traversal kernel cut at the fingerprint read, and the
-    thread-per-traversal restatement of the oracle's stepper — the latter without speculation (the default) and with
-    one or two queue heads expanded speculatively per step: the committed state must not depend on it"""
+    """the three step kernels of shard.hip: sixteen lanes per traversal (the default), the single-GPU traversal kernel
+    cut at the fingerprint read, and the thread-per-traversal restatement of the oracle's stepper — row and thread
+    without speculation (the thread engine's default) and with one or two queue heads expanded speculatively per step
+    (two is the row engine's default): the committed state must not depend on it"""
     name, _, spec = request.param.partition("-spec")
     monkeypatch.setenv("RADHIP_SHARD_ENGINE", name)
     if spec:
@@ -329,10 +330,11 @@ def test_link_resident_equals_add(gpu, oracle):
         assert np.array_equal(x, y)
 
 
-def test_speculation_cuts_steps_not_results(gpu, oracle, monkeypatch):
+@pytest.mark.parametrize("eng", ["row", "thread"])
+def test_speculation_cuts_steps_not_results(gpu, oracle, monkeypatch, eng):
     """Speculative score prefetch: fewer frontier steps, identical committed state."""
     from rad_amd.device import DeviceShard, RcclComm
-    monkeypatch.setenv("RADHIP_SHARD_ENGINE", "thread")
+    monkeypatch.setenv("RADHIP_SHARD_ENGINE", eng)
     n, nq, nts = 60000, 16, 6000
     X, g, full, Qall = _row_sharded_setup(oracle, n, nts, 1, nq, mode=2, seed=11)
     comm = RcclComm(0, 1, RcclComm.unique_id(), 0)
@@ -382,14 +384,15 @@ def test_pair_of_groups_on_two_streams(gpu, oracle, monkeypatch):
             assert np.array_equal(nodes, want.pop_nodes) and np.array_equal(lv, want.pop_levels)
 
 
-def test_loop_fails_safe(gpu, oracle, monkeypatch):
+@pytest.mark.parametrize("eng", ["row", "thread"])
+def test_loop_fails_safe(gpu, oracle, monkeypatch, eng):
     """A host-side failure in the middle of radhip_shard_run (injected) and a device-side one (a queue that is
     too small): both return an error promptly, leak nothing that blocks the next run, and a fresh shard on the
     same index works afterwards."""
     from rad_amd import _lib
     from rad_amd._lib import RadHipError
     from rad_amd.device import DeviceShard, RcclComm
-    monkeypatch.setenv("RADHIP_SHARD_ENGINE", "thread")
+    monkeypatch.setenv("RADHIP_SHARD_ENGINE", eng)
     n, nq, nts = 20000, 8, 4000
     X, g, full, Qall = _row_sharded_setup(oracle, n, nts, 1, nq, mode=2, seed=31)
     comm = RcclComm(0, 1, RcclComm.unique_id(), 0)

@@ -17,16 +17,19 @@
 // engine, tests/test_gpu_sharded.py through these kernels).  What is exchanged per step and rank:
 // nq x W candidate slots (4 B each) out, nq x W packed (and | or << 16) scores back.
 //
-// Two step engines, same results.  "thread" (the default): shard_step_kernel below, one thread per traversal, an
-// 8-ary heap and open-addressed sets in HBM — the oracle's stepper restated (oracle/rad_oracle.c
-// orc_stepper_step).  "wave" (RADHIP_SHARD_ENGINE=wave; adjacency rows of at most 16 slots): trav4_kernel's
-// sharded form (traverse4.inc, SH = true) — the single-GPU kernel with its three-level queue and tables, four
-// traversals per wavefront, cut at the fingerprint read and resumed by the next launch.  A step is a launch
-// that ends when its slowest traversal has its candidates out, so what counts is the worst-case latency of ONE
-// pop, not throughput: the heap's O(log n) dependent reads are evenly short, the wave kernel's register/LDS
-// queue pays a state restore + save per launch and now and then a 256-key sort or a pass over its far runs.
-// Measured on one MI355X (profiles/r02/README.md §5): thread 66 / 97 us per step at 8192 / 30720 traversals,
-// wave 91 / 171 us — the wave engine stays as the second implementation the tests cross-check.
+// Three step engines, same results.  "row" (the default since round 3): shard_step_row_kernel, sixteen lanes per
+// traversal, a 16-ary heap whose levels are 128-B lines, neighbours probed one per lane, state in HBM.  "thread"
+// (RADHIP_SHARD_ENGINE=thread): shard_step_kernel, one thread per traversal, an 8-ary heap and open-addressed sets in HBM
+// — the oracle's stepper restated (oracle/rad_oracle.c orc_stepper_step).  "wave" (RADHIP_SHARD_ENGINE=wave; adjacency
+// rows of at most 16 slots): trav4_kernel's sharded form (traverse4.inc, SH = true) — the single-GPU kernel with its
+// three-level queue and tables, four traversals per wavefront, cut at the fingerprint read and resumed by the next
+// launch.  A step is a launch that ends when its slowest traversal has its candidates out, so what counts is the
+// worst-case latency of ONE pop, not throughput: the heaps' O(log n) dependent reads are evenly short, the wave
+// kernel's register/LDS queue pays a state restore + save per launch and now and then a 256-key sort or a pass over
+// its far runs.  Measured on one MI355X, 20M rows, world 1 (profiles/r03/sharded_engines): without speculation the row
+// engine takes 75 us per step at 16384 traversals and 119 at 32768, the thread engine 87 and 107 (wave, round 2: 91 /
+// 171 at 8192 / 30720); with two speculative queue heads per step (the row engine's default) the row engine needs 0.54 x
+// the steps at 1.6 x the time each: 186 / 228 / 256 M expansions/s at 16384 / 32768 / 49152 traversals per rank.
 #include "common.h"
 #include "comm.h"
 

@@ -709,7 +709,8 @@ struct radhip_traversal {
     size_t ht_bytes = 0, ut_bytes = 0, scored_bytes = 0, pq_bytes = 0, stg_bytes = 0, runs_bytes = 0,
            rhead_bytes = 0, rsave_bytes = 0, hdr_bytes = 0, log_bytes = 0;
     bool fresh_tables = true;   // tables not cleared yet (first upload)
-    bool use4 = false;   // trav4_kernel (four traversals per wave) when every adjacency row is <= 16 wide
+    bool use4 = false;   // trav4_kernel (four traversals per wave)
+    bool wide = false;   // ... its WIDE form: adjacency rows of 17..64 slots, walked in chunks of 16
     bool use_gt = false; // grouped visited/scored table (needs the index's graph-locality layout)
     bool use_bt = false; // bucket table: 16-B buckets of four entries, one request per probe (trav4_kernel's default)
     size_t bt_bytes = 0;
@@ -827,12 +828,22 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
         t->use4 = true;
     } else {
         const int forced = trav_forced_kernel();
-        t->use4 = trav4_shape_ok(idx) && forced != 1;
+        // rows wider than 16 slots (connectivity > 8): trav4_kernel's WIDE form walks a row in chunks of 16 (bucket table
+        // only: RADHIP_TABLE=hash / group keep such an index on trav_kernel)
+        const char *tb = getenv("RADHIP_TABLE");
+        const bool narrow = trav4_shape_ok(idx), wide = !narrow && idx->cap0 <= 64 && idx->M <= 64 && !(tb && (tb[0] == 'h' || tb[0] == 'g'));
+        // measured (profiles/r03): rows of 32 slots (the reference notebook's connectivity 16) are 14-40 % faster on the WIDE
+        // form than on trav_kernel; rows of 64 (BASELINE config[4]: four chunks, four gather passes per pop) are not —
+        // those stay on trav_kernel unless RADHIP_TRAV=4 asks
+        const bool wide_auto = wide && idx->cap0 <= 32 && idx->M <= 32;
+        t->use4 = (narrow || (forced == 4 ? wide : wide_auto)) && forced != 1;
+        t->wide = t->use4 && wide;
         if (t->use4 && forced != 4) {   // auto: four per wave beyond one resident round (and a quarter) of trav_kernel
             uint32_t cap1 = 0;
             int rc1 = trav_capacity_of(idx, false, &cap1);
             if (rc1 != RADHIP_OK) { delete t; return rc1; }
             t->use4 = (uint64_t)nq * 4ull > 5ull * cap1;
+            t->wide = t->use4 && wide;
         }
     }
     const uint64_t n_top = idx->n_top;
@@ -880,7 +891,7 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
         const char *e = getenv("RADHIP_TABLE");
         const bool force_group = e && e[0] == 'g';
         const uint32_t gt_log2 = std::max<uint32_t>(7, log2_ceil((scored_cap * 5 + 31) / 32));
-        const bool can = idx->layout_valid && idx->d_adjx0 && t->use4 && gt_log2 <= 17 && !sharded;
+        const bool can = idx->layout_valid && idx->d_adjx0 && t->use4 && !t->wide && gt_log2 <= 17 && !sharded;
         t->use_gt = can && force_group;
         P.gt_log2 = gt_log2;
         // Bucket table: trav4_kernel's default (RADHIP_TABLE=hash keeps the one-entry-per-probe table, for A/B runs).
@@ -889,7 +900,7 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
         t->use_bt = t->use4 && !t->use_gt && !sharded && !force_hash;
         P.bt_log2 = std::max<uint32_t>(6, log2_ceil((scored_cap * 5 + 7) / 8));
         P.bt_sbits = std::max<uint32_t>(8, log2_ceil(idx->g_n + 2));
-        if (P.bt_sbits > 30 || P.bt_log2 > 28) t->use_bt = false;
+        if (P.bt_sbits > 30 || P.bt_log2 > 28) { t->use_bt = false; if (t->wide) { t->wide = false; t->use4 = false; } }
         if (t->use_bt) t->epoch_max = (1u << (31u - P.bt_sbits)) - 1u;
         P.adjx0 = idx->d_adjx0; P.adjxU = idx->d_adjxU; P.topx = idx->d_topx; P.lid = idx->d_lid;
     }
@@ -1004,12 +1015,15 @@ static int trav_launch(radhip_traversal *t) {
 #define RH_K4G(LPR) trav4_kernel<LPR, true>
 #define RH_K4H(LPR) trav4_kernel<LPR, false>
 #define RH_K4B(LPR) trav4_kernel<LPR, false, false, true>
+#define RH_K4W(LPR) trav4_kernel<LPR, false, false, true, true>
 #define RH_K1H(LPR) trav_kernel<LPR>
-    if (t->use4 && t->use_gt) { RH_TRAV_CASES(RH_K4G, (t->nq + 3u) / 4u) }
+    if (t->use4 && t->wide) { RH_TRAV_CASES(RH_K4W, (t->nq + 3u) / 4u) }
+    else if (t->use4 && t->use_gt) { RH_TRAV_CASES(RH_K4G, (t->nq + 3u) / 4u) }
     else if (t->use4 && t->use_bt) { RH_TRAV_CASES(RH_K4B, (t->nq + 3u) / 4u) }
     else if (t->use4) { RH_TRAV_CASES(RH_K4H, (t->nq + 3u) / 4u) }
     else { RH_TRAV_CASES(RH_K1H, t->nq) }
 #undef RH_K4B
+#undef RH_K4W
 #undef RH_K4G
 #undef RH_K4H
 #undef RH_K1H
@@ -1439,7 +1453,10 @@ extern "C" int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t 
     if (!idx || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
     RH_TRY(rh_ensure_device(idx));
-    return trav_capacity_of(idx, trav4_shape_ok(idx) && trav_forced_kernel() != 1, out);
+    const char *tb = getenv("RADHIP_TABLE");
+    const int forced = trav_forced_kernel();
+    const bool wide_ok = idx->cap0 <= (forced == 4 ? 64u : 32u) && idx->M <= (forced == 4 ? 64u : 32u) && !(tb && (tb[0] == 'h' || tb[0] == 'g'));
+    return trav_capacity_of(idx, (trav4_shape_ok(idx) || wide_ok) && forced != 1, out);
 }
 
 // 4 = trav4_kernel (four traversals per wavefront), 1 = trav_kernel

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """The reference's own index parameters (examples/DUDEZ_example.ipynb:165-166, 183-189: 1024-bit Morgan fingerprints,
 connectivity = 16 -> level-0 rows of 32 slots, expansion_add = 400) on the synthetic hierarchical corpus: build time,
-recall@10, and the traversal kernel's rate and algorithmic fraction (rows wider than 16 slots run on trav_kernel, one
-traversal per wavefront).      python scripts/notebook_shape.py [n_rows] [connectivity] [expansion_add] [ndim]"""
+recall@10, and the rate and algorithmic fraction of both traversal kernels (trav_kernel: one traversal per wavefront, a 64-lane row;
+trav4_kernel's WIDE form: four per wavefront, a row walked in chunks of 16).      python scripts/notebook_shape.py [n_rows] [connectivity] [expansion_add] [ndim]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -30,11 +30,16 @@ for ef in (128, 400):
     rec[ef] = float(np.mean([len(set(s[i]) & set(es[i])) / 10 for i in range(256)]))
 print(f"n={n} {ndim}-bit connectivity={M} (level-0 width {2 * M}) expansion_add={ef_add}: Index build {tb:.1f} s ({n / tb / 1e6:.2f} M inserts/s), "
       f"recall@10 ef128 {rec[128]:.3f} ef400 {rec[400]:.3f}", flush=True)
-cap = idx.traversal_capacity()
 B = idx.info().row_stride
-for nq in (cap, 2 * cap):
-    tq = idx.read_vectors(int(rng.integers(0, n - nq)), nq)
-    t = DeviceTraversal(idx, tq, nts)
+for kern, mult in (("1", 1), ("1", 2), ("4", 1), ("4", 2)):
+    os.environ["RADHIP_TRAV"] = kern
+    cap = idx.traversal_capacity()
+    nq = cap * mult
+    try:
+        t = DeviceTraversal(idx, idx.read_vectors(int(rng.integers(0, n - nq)), nq), nts)
+    except Exception as e:   # (state of the larger batches may not fit)
+        print(f"  {nq} traversals (RADHIP_TRAV={kern}): {e}", flush=True)
+        continue
     t.run()
     t.reset(idx.read_vectors(int(rng.integers(0, n - nq)), nq))     # second batch: the timed one
     t.run()
@@ -42,5 +47,5 @@ for nq in (cap, 2 * cap):
     pops, ev = int(st.n_pops.sum()), int(st.n_scored.sum())
     alg = (ev * (B + 4) + pops * 4) / (ms * 1e-3) / 1e9
     print(f"  {nq} traversals to {nts} ({t.kernel}, table {t.table}): {ms:.1f} ms, {pops / ms / 1e3:.0f} M expansions/s, {ev / ms / 1e6:.2f} G evals/s, "
-          f"{ev / pops:.1f} evals/expansion, algorithmic {alg:.0f} GB/s = {alg / 8000:.3f} of 8 TB/s", flush=True)
+          f"{ev / pops:.1f} evals/expansion, algorithmic {alg:.0f} GB/s = {alg / 8000:.3f} of 8 TB/s; state {t.state_bytes() / nq / 1e6:.2f} MB/traversal", flush=True)
     t.close()

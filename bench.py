@@ -4,8 +4,8 @@
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on; it fits one GPU):
 100M x 1024-bit fingerprints resident in HBM; an HNSW graph built over them on the GPU by the library's
 own insert kernels (connectivity 8, level-0 width 16, expansion_add 64: ~30 s); `nq` independent
-best-first RAD traversals (Tanimoto-scored; nq defaults to twice what the device holds resident at
-once: 2 x 16384 on MI355X), each run to n_to_score = 100k.  One "step" = one pass of the hot path over
+best-first RAD traversals (Tanimoto-scored; nq defaults to four times what the device holds resident at
+once: 4 x 16384 on MI355X, 217 GB of traversal state beside the 20 GB index), each run to n_to_score = 100k.  One "step" = one pass of the hot path over
 one batch of nq queries: state re-arm (query upload, epoch bump) + traversal kernel launch to completion.
 The fingerprints are synthetic (closed-form generator on the device: no dataset can be downloaded here);
 `--corpus-mode 2` (default) is the hierarchical corpus — neighbourhood structure at every scale, the
@@ -63,7 +63,7 @@ def parse_args():
     ap.add_argument("--ndim", type=int, default=1024)
     ap.add_argument("--connectivity", type=int, default=8)
     ap.add_argument("--nq", type=int, default=0,
-                    help="concurrent traversals per GPU per step (0 = twice what the device holds resident at once)")
+                    help="concurrent traversals per GPU per step (0 = four times what the device holds resident at once, memory permitting)")
     ap.add_argument("--n-to-score", type=int, default=100_000)
     ap.add_argument("--corpus-mode", type=int, default=2,
                     help="0 dense Bernoulli(0.5), 1 two-level clustered sparse (round 1), 2 hierarchical sparse")
@@ -652,13 +652,15 @@ def main():
     B = info.row_stride
     n_batches = args.warmup + args.steps
     if args.nq <= 0:
-        # two resident rounds: traversals end at different times and the second round's workgroups take over
-        # the slots the early finishers leave — or as many as the device has room for beside the index (the state
-        # of a traversal to n_to_score = 100k is ~5 MB; six wavefronts per SIMD hold 24576 traversals resident)
+        # four times what the device holds resident at once, or as many as it has room for beside the index (3.3 MB of
+        # state per traversal to n_to_score = 100k): the traversals of a batch differ in length (+-18 %, the longest 2 x
+        # the mean) and a launch ends with its longest one running alone — ~130 ms whatever the batch.  Measured on 20M
+        # rows: 1.32 / 1.44 / 1.62 G expansions/s at 1 / 2 / 4 resident rounds per launch; the marginal rate between
+        # them is 1.86 G (profiles/r03)
         from rad_amd._lib import RadHipError, E_NOMEM
         from rad_amd.device import DeviceTraversal
         cap = idx.traversal_capacity()
-        for mult in (2.0, 1.5, 1.0):
+        for mult in (4.0, 3.0, 2.0, 1.5, 1.0):
             args.nq = int(cap * mult)
             try:
                 probe = DeviceTraversal(idx, idx.read_vectors(0, args.nq), args.n_to_score)

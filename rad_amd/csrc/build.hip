@@ -596,7 +596,7 @@ static int add_impl(radhip_index *idx, const uint8_t *rows, uint64_t count, uint
             uint4 *nfp = nullptr;
             hipError_t e = hipMalloc((void **)&nfp, ncap * idx->row_stride);
             if (e != hipSuccess && ncap > need) { ncap = need; e = hipMalloc((void **)&nfp, ncap * idx->row_stride); }   // tight on memory: exact size
-            if (e != hipSuccess) { rollback(); RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP, "hipMalloc for %llu rows failed: %s", (unsigned long long)need, hipGetErrorString(e)); }
+            if (e != hipSuccess) { (void)hipGetLastError(); rollback(); RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP, "hipMalloc for %llu rows failed: %s", (unsigned long long)need, hipGetErrorString(e)); }
             if (idx->d_fp && first && (hipMemcpyAsync(nfp, idx->d_fp, first * idx->row_stride, hipMemcpyDeviceToDevice, idx->stream) != hipSuccess ||
                                        hipStreamSynchronize(idx->stream) != hipSuccess)) {
                 (void)hipFree(nfp); rollback(); RH_FAIL(RADHIP_E_HIP, "device copy of the corpus failed");
@@ -678,7 +678,7 @@ static int add_impl(radhip_index *idx, const uint8_t *rows, uint64_t count, uint
         free_req();
         if (!committed) rollback();
     };
-#define BH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { radhip_set_error("%s failed: %s", #x, hipGetErrorString(e_)); cleanup(); return e_ == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP; } } while (0)
+#define BH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { radhip_set_error("%s failed: %s", #x, hipGetErrorString(e_)); (void)hipGetLastError(); cleanup(); return e_ == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP; } } while (0)
     BH(hipMalloc((void **)&d_vis, (bmax << vlog2) * 4));
     BH(hipMalloc((void **)&d_status, bmax * 4));
     BH(hipMalloc((void **)&d_req_count, 8));
@@ -852,7 +852,7 @@ extern "C" int radhip_search(radhip_index_t *idx, const uint8_t *queries, uint32
         void *ps[] = {dq, dpop, dvis, ds, da, dorr, dc, de, dp, dst};
         for (void *p : ps) if (p) (void)hipFree(p);
     };
-#define SH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { radhip_set_error("%s failed: %s", #x, hipGetErrorString(e_)); cleanup(); return e_ == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP; } } while (0)
+#define SH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { radhip_set_error("%s failed: %s", #x, hipGetErrorString(e_)); (void)hipGetLastError(); cleanup(); return e_ == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP; } } while (0)
     SH(hipMalloc((void **)&dq, padded.size()));
     SH(hipMalloc((void **)&dpop, (size_t)nq * 4));
     SH(hipMalloc((void **)&dvis, ((size_t)nq << vlog2) * 4));

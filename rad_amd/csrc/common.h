@@ -27,6 +27,7 @@ void radhip_set_error(const char *fmt, ...);
         if (e_ != hipSuccess) {                                                   \
             radhip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
                              __FILE__, __LINE__);                                 \
+            (void)hipGetLastError();   /* (the runtime keeps a failed call as its "last error": a later launch check would report it again) */ \
             return (e_ == hipErrorOutOfMemory) ? RADHIP_E_NOMEM : RADHIP_E_HIP;   \
         }                                                                         \
     } while (0)

@@ -961,6 +961,7 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
         if (e != hipSuccess) {
             radhip_set_error("hipMalloc(%zu) for the sharded traversal state failed: %s", bytes, hipGetErrorString(e));
             rc = e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP;
+            (void)hipGetLastError();
             return;
         }
         s->state_bytes += bytes;

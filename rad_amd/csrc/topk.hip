@@ -251,7 +251,7 @@ extern "C" int radhip_tanimoto_topk(radhip_index_t *idx, const uint8_t *queries,
         void *ps[] = {dq, dpop, ds, da, dorr, dc, dcand};
         for (void *p : ps) if (p) (void)hipFree(p);
     };
-#define TK_G(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { radhip_set_error("%s failed: %s", #x, hipGetErrorString(e_)); cleanup(); return e_ == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP; } } while (0)
+#define TK_G(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { radhip_set_error("%s failed: %s", #x, hipGetErrorString(e_)); (void)hipGetLastError(); cleanup(); return e_ == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP; } } while (0)
     TK_G(hipMalloc((void **)&dq, padded.size()));
     TK_G(hipMalloc((void **)&dpop, (size_t)nq * 4));
     TK_G(hipMalloc((void **)&ds, (size_t)pass * k * 4));

@@ -116,6 +116,7 @@ struct TravParams {
     uint2 *runs;                   // [nq * max_runs] {pos, end}
     unsigned long long *rhead;     // [nq * MAX_RUNS] head key of every run (INF = exhausted)
     unsigned long long *midpool;   // trav4_kernel: [nq * 256] the sorted mid run of every traversal
+    uint32_t *q_next;              // trav4_kernel: the next traversal of the batch a free row takes (zeroed before every launch)
     uint32_t *poplog_nodes;
     uint8_t *poplog_levels;
     uint64_t poplog_cap;
@@ -710,6 +711,7 @@ struct radhip_traversal {
            rhead_bytes = 0, rsave_bytes = 0, hdr_bytes = 0, log_bytes = 0;
     bool fresh_tables = true;   // tables not cleared yet (first upload)
     bool use4 = false;   // trav4_kernel (four traversals per wave)
+    uint32_t resident4 = 0;   // traversals trav4_kernel holds resident on this device (grid = resident4 / 4 wavefronts)
     bool wide = false;   // ... its WIDE form: adjacency rows of 17..64 slots, walked in chunks of 16
     bool use_gt = false; // grouped visited/scored table (needs the index's graph-locality layout)
     bool use_bt = false; // bucket table: 16-B buckets of four entries, one request per probe (trav4_kernel's default)
@@ -787,6 +789,7 @@ extern "C" int radhip_traversal_destroy(radhip_traversal_t *t) {
     if (t->P.runs) (void)hipFree(t->P.runs);
     if (t->P.rhead) (void)hipFree(t->P.rhead);
     if (t->P.midpool) (void)hipFree(t->P.midpool);
+    if (t->P.q_next) (void)hipFree(t->P.q_next);
     if (t->P.r_save) (void)hipFree(t->P.r_save);
     if (t->P.sh_pend_h) (void)hipFree(t->P.sh_pend_h);
     if (t->P.poplog_nodes) (void)hipFree(t->P.poplog_nodes);
@@ -925,6 +928,7 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
         if (e_ != hipSuccess) {                                                            \
             radhip_set_error("hipMalloc(%zu) for traversal state failed: %s", (size_t)(bytes), hipGetErrorString(e_)); \
             rc = e_ == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP;                \
+            (void)hipGetLastError();                                                       \
         } else t->state_bytes += (bytes);                                                  \
     } while (0)
     RH_A(t->d_queries, (size_t)nq * idx->row_stride);
@@ -939,6 +943,7 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
     if (rc == 0) RH_A(P.runs, t->runs_bytes);
     if (rc == 0) RH_A(P.rhead, t->rhead_bytes);
     if (rc == 0) RH_A(P.midpool, (size_t)nq * 256 * 8);
+    if (rc == 0) RH_A(P.q_next, 64);
     if (rc == 0) RH_A(P.r_save, t->rsave_bytes);
     if (rc == 0 && sharded) RH_A(P.sh_pend_h, (size_t)nq * 16 * 4);
     if (rc == 0 && (flags & RADHIP_TRAV_LOG_POPS)) {
@@ -1003,6 +1008,14 @@ static int trav_launch(radhip_traversal *t) {
 #else
     t->P.prof = nullptr;
 #endif
+    // trav4_kernel: as many wavefronts as the device holds resident; their rows take the traversals of the batch from
+    // a counter, one after the other (traverse4.inc)
+    uint32_t grid4 = (t->nq + 3u) / 4u;
+    if (t->use4) {
+        if (t->resident4 == 0) { uint32_t c = 0; RH_TRY(trav_capacity_of(idx, true, &c)); t->resident4 = c ? c : 4u; }
+        grid4 = std::min<uint32_t>(grid4, t->resident4 / 4u);
+        RH_HIP(hipMemsetAsync(t->P.q_next, 0, 4, idx->stream));
+    }
     RH_HIP(hipEventRecord(t->ev0, idx->stream));
 #define RH_TRAV_CASES(KERNEL, GRID)                                                                              \
     switch (idx->lpr) {                                                                                          \
@@ -1017,10 +1030,10 @@ static int trav_launch(radhip_traversal *t) {
 #define RH_K4B(LPR) trav4_kernel<LPR, false, false, true>
 #define RH_K4W(LPR) trav4_kernel<LPR, false, false, true, true>
 #define RH_K1H(LPR) trav_kernel<LPR>
-    if (t->use4 && t->wide) { RH_TRAV_CASES(RH_K4W, (t->nq + 3u) / 4u) }
-    else if (t->use4 && t->use_gt) { RH_TRAV_CASES(RH_K4G, (t->nq + 3u) / 4u) }
-    else if (t->use4 && t->use_bt) { RH_TRAV_CASES(RH_K4B, (t->nq + 3u) / 4u) }
-    else if (t->use4) { RH_TRAV_CASES(RH_K4H, (t->nq + 3u) / 4u) }
+    if (t->use4 && t->wide) { RH_TRAV_CASES(RH_K4W, grid4) }
+    else if (t->use4 && t->use_gt) { RH_TRAV_CASES(RH_K4G, grid4) }
+    else if (t->use4 && t->use_bt) { RH_TRAV_CASES(RH_K4B, grid4) }
+    else if (t->use4) { RH_TRAV_CASES(RH_K4H, grid4) }
     else { RH_TRAV_CASES(RH_K1H, t->nq) }
 #undef RH_K4B
 #undef RH_K4W
@@ -1114,6 +1127,7 @@ static int trav_grow_upper(radhip_traversal *t) {
         if (n_pq) (void)hipFree(n_pq);
         if (n_pl) (void)hipFree(n_pl);
         if (n_plv) (void)hipFree(n_plv);
+        (void)hipGetLastError();
         (void)hipGetLastError();
         RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP, "growing the traversal state failed: %s", hipGetErrorString(e));
     }

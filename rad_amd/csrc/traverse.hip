@@ -117,6 +117,7 @@ struct TravParams {
     unsigned long long *rhead;     // [nq * MAX_RUNS] head key of every run (INF = exhausted)
     unsigned long long *midpool;   // trav4_kernel: [nq * 256] the sorted mid run of every traversal
     uint32_t *q_next;              // trav4_kernel: the next traversal of the batch a free row takes (zeroed before every launch)
+    uint32_t q_static;             // 1: a row keeps the traversal its block index names and takes no other (grid = nq / 4)
     uint32_t *poplog_nodes;
     uint8_t *poplog_levels;
     uint64_t poplog_cap;
@@ -1013,7 +1014,15 @@ static int trav_launch(radhip_traversal *t) {
     uint32_t grid4 = (t->nq + 3u) / 4u;
     if (t->use4) {
         if (t->resident4 == 0) { uint32_t c = 0; RH_TRY(trav_capacity_of(idx, true, &c)); t->resident4 = c ? c : 4u; }
-        grid4 = std::min<uint32_t>(grid4, t->resident4 / 4u);
+        // Rows that take their traversals from the counter: +2-4 % on rows of <= 16 slots (no row waits for the longest of
+        // its wavefront's four), but -25 % and worse on the WIDE form, whose rows then walk through their traversals out
+        // of phase (measured in one binary, profiles/r03/wide_rows_static_vs_counter.log): wide rows keep the static
+        // assignment.  RADHIP_TRAV_STATIC=1 / 0 forces either.
+        t->P.q_static = t->wide ? 1u : 0u;
+        if (const char *e = getenv("RADHIP_TRAV_STATIC")) t->P.q_static = e[0] == '1' ? 1u : 0u;
+        if (!t->P.q_static) grid4 = std::min<uint32_t>(grid4, t->resident4 / 4u);
+        // (test hook: a grid of a few wavefronts, so that small batches exercise rows that take many traversals in a row)
+        if (const char *e = getenv("RADHIP_TEST_GRID")) { const int v = atoi(e); if (v > 0 && !t->P.q_static) grid4 = std::min<uint32_t>(grid4, (uint32_t)v); }
         RH_HIP(hipMemsetAsync(t->P.q_next, 0, 4, idx->stream));
     }
     RH_HIP(hipEventRecord(t->ev0, idx->stream));

@@ -31,7 +31,7 @@ for ef in (128, 400):
 print(f"n={n} {ndim}-bit connectivity={M} (level-0 width {2 * M}) expansion_add={ef_add}: Index build {tb:.1f} s ({n / tb / 1e6:.2f} M inserts/s), "
       f"recall@10 ef128 {rec[128]:.3f} ef400 {rec[400]:.3f}", flush=True)
 B = idx.info().row_stride
-for kern, mult in (("1", 1), ("1", 2), ("4", 1), ("4", 2)):
+for kern, mult in (("1", 1), ("1", 2), ("4", 1), ("4", 2), ("4", 4)):
     os.environ["RADHIP_TRAV"] = kern
     cap = idx.traversal_capacity()
     nq = cap * mult

@@ -96,6 +96,50 @@ def _check_traversal(oracle, idx, graph, X, Q, n_to_score):
     t.close()
 
 
+@pytest.mark.parametrize("grid,static", [(1, "0"), (2, "0"), (3, "1")])
+@pytest.mark.parametrize("table", ["bucket", "hash", "group"])
+def test_rows_take_traversals_from_the_counter(gpu, oracle, monkeypatch, grid, static, table):
+    """trav4_kernel launches as many wavefronts as the device holds resident and their rows take the traversals of the batch
+    one after the other; a grid of one or two wavefronts (test hook) makes every row work through many traversals of
+    different lengths — and resume them in rounds — with the same results as one row per traversal."""
+    from rad_amd.device import DeviceTraversal
+    monkeypatch.setenv("RADHIP_TRAV", "4")
+    monkeypatch.setenv("RADHIP_TRAV_STATIC", static)
+    if table != "bucket":
+        monkeypatch.setenv("RADHIP_TABLE", table)
+    n, nq = 6000, 37
+    idx = _mk_index(1024, 8, 16)
+    idx.synth_vectors(n, seed=5, mode=2)
+    idx.link_resident(seed=9, max_batch=512)
+    X = idx.read_vectors(0, n)
+    levels, adj0, upper_row, adjU = idx.read_graph()
+    inf = idx.info()
+    g = oracle.Graph(n, 16, 8, int(inf.max_level), int(inf.entry), levels, adj0, upper_row, adjU)
+    rng = np.random.default_rng(3)
+    Q = X[rng.integers(0, n, nq)].copy()
+    Q[3] = 0
+    nts = 900
+    want = [oracle.rad_traverse(g, X, Q[i], nts) for i in range(nq)]
+    monkeypatch.setenv("RADHIP_TEST_GRID", str(grid))
+    t = DeviceTraversal(idx, Q, nts, log_pops=True)
+    assert t.kernel == "trav4_kernel"
+    if static == "0":   # in rounds: every launch, every row lets go of and takes up traversals that are half done
+        rounds = 0
+        while t.run(max_pops=40) and rounds < 200:
+            rounds += 1
+        assert rounds >= 3
+    else:
+        assert t.run() == 0
+    st = t.stats()
+    for i in range(nq):
+        s, a, o = t.results(i)
+        nodes, lv = t.pop_log(i)
+        assert np.array_equal(nodes, want[i].pop_nodes) and np.array_equal(lv, want[i].pop_levels), i
+        assert np.array_equal(s, want[i].slots) and np.array_equal(a, want[i].and_cnt) and np.array_equal(o, want[i].or_cnt), i
+        assert st.n_pops[i] == want[i].n_pops and st.n_nbr[i] == want[i].n_nbr
+    t.close()
+
+
 @pytest.mark.parametrize("ndim,n,M,cap0,n_to_score", [
     (1024, 4096, 8, 16, 1000),
     (1024, 30000, 8, 16, 5000),

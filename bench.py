@@ -80,8 +80,11 @@ def parse_args():
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="replicas", help="which N > 1 leg `value` reports (both always run)")
     ap.add_argument("--sharded-timeout", type=float, default=420.0,
                     help="seconds the sharded leg may take before the line is printed without it (a hung collective must not cost the run)")
-    ap.add_argument("--sharded-nq", type=int, default=32768,
-                    help="traversals per rank and step of the sharded leg (a step costs 87 us at 16384, 106 us at 32768: the more the better; 4.5 MB of state each)")
+    ap.add_argument("--sharded-nq", type=int, default=65536,
+                    help="traversals per rank and batch of the sharded leg (0.8 MB each for the scored list; the slots hold the rest)")
+    ap.add_argument("--sharded-slots", type=int, default=32768,
+                    help="slots per rank of the sharded leg (queue + sets of a traversal: 3.6 MB); a slot whose traversal is done takes "
+                         "the next one of the batch (0 = one slot per traversal)")
     ap.add_argument("--sharded-groups", type=int, default=1, choices=[1, 2],
                     help="groups the sharded traversals of a rank are split into: 2 = two streams and two communicators, one group's "
                          "step kernel overlaps the other's collectives (RCCL exchange only)")
@@ -357,10 +360,11 @@ def synth_queries(args, device, firsts, count, mode):
 
 
 def reference_sample(args, full, Qall_last, world, nq, ns, nfull):
-    """The single-GPU kernel on an index that holds the WHOLE corpus, for the first `ns` traversals of every rank's
-    last batch: counters of all of them, full scored lists of the first `nfull` per rank."""
+    """The single-GPU kernel on an index that holds the WHOLE corpus, for the LAST `ns` traversals of every rank's
+    last batch (with fewer slots than traversals those are the ones that slots took over from finished ones): counters of
+    all of them, full scored lists of the first `nfull` of them per rank."""
     from rad_amd.device import DeviceTraversal
-    Q = np.concatenate([Qall_last[r * nq:r * nq + ns] for r in range(world)])
+    Q = np.concatenate([Qall_last[(r + 1) * nq - ns:(r + 1) * nq] for r in range(world)])
     ref = DeviceTraversal(full, Q, args.n_to_score)
     ref.run(0)
     st = ref.stats()
@@ -382,6 +386,11 @@ def drive_shards(args, grp, rank, world, idx, first, count, Qall, comms, barrier
     def group_queries(Q, g):
         return np.concatenate([Q[r * nq + g * nqg:r * nq + (g + 1) * nqg] for r in range(world)])
 
+    # fewer slots than traversals (the product loop only: the host-staged exchange does not carry the slots' traversal numbers)
+    if not use_host and 0 < args.sharded_slots // G < nqg:
+        os.environ["RADHIP_SHARD_SLOTS"] = str(args.sharded_slots // G)
+    else:
+        os.environ.pop("RADHIP_SHARD_SLOTS", None)
     shards = [DeviceShard(idx, rank, world, first, count, group_queries(Qall[0], g), args.n_to_score, own_stream=g > 0) for g in range(G)]
     res = {"steps": 0, "bytes": 0, "pops": 0, "evals": 0, "spec_asked": 0, "spec_used": 0, "spec_hits": 0}
     last = None
@@ -398,7 +407,7 @@ def drive_shards(args, grp, rank, world, idx, first, count, Qall, comms, barrier
             steps = shards[0].run(comms[0]) if G == 1 else shards[0].run_pair(comms[0], shards[1], comms[1])
             xb = sum(sh.timing()[3] for sh in shards)
         sts = [sh.stats() for sh in shards]
-        last = sts[0]
+        last = sts[-1]
         sp = [sh.speculation() for sh in shards]
         return (steps, xb, sum(int(st.n_pops.sum()) for st in sts), sum(int(st.n_scored.sum()) for st in sts),
                 sum(x[1] for x in sp), sum(x[2] for x in sp), sum(x[3] for x in sp))
@@ -417,17 +426,19 @@ def drive_shards(args, grp, rank, world, idx, first, count, Qall, comms, barrier
     res["spec_depth"] = shards[0].speculation()[0]
     res["width"] = shards[0].width
     res["engine"] = shards[0].engine
+    res["slots"] = sum(sh.slots for sh in shards)
     res["groups"] = G
     res["state_bytes"] = sum(sh.state_bytes() for sh in shards)
-    # parity gate: the first ns traversals of this rank (they ride in group 0) against the single-GPU kernel on the
-    # whole corpus — all three counters, and the complete scored lists (slots and both counts) of the first nfull
+    # parity gate: the last ns traversals of this rank (they ride in the last group) against the single-GPU kernel on the
+    # whole corpus — all three counters, and the complete scored lists (slots and both counts) of the first nfull of them
     good = tot = 0
     if ref is not None:
-        k = min(ns, nqg)
-        good = int(((last.n_scored[:k] == ref["scored"][rank][:k]) & (last.n_pops[:k] == ref["pops"][rank][:k]) & (last.n_nbr[:k] == ref["nbr"][rank][:k])).sum())
+        assert ns <= nqg
+        k, o = ns, nqg - ns
+        good = int(((last.n_scored[o:] == ref["scored"][rank]) & (last.n_pops[o:] == ref["pops"][rank]) & (last.n_nbr[o:] == ref["nbr"][rank])).sum())
         tot = k
         for i in range(min(nfull, k)):
-            got, want = shards[0].results(i), ref["lists"][(rank, i)]
+            got, want = shards[-1].results(o + i), ref["lists"][(rank, i)]
             tot += 1
             good += int(all(np.array_equal(x, y) for x, y in zip(got, want)))
     res["parity_ok"], res["parity_n"] = good, tot
@@ -448,7 +459,7 @@ def run_sharded_leg(args, idx, grp, rank, world, local_rank, barrier):
     firsts = [int(qrng.integers(0, n - world * nq)) for _ in range(n_batches)]
     Qall = [idx.read_vectors(f, world * nq) for f in firsts]          # rank-major, identical on every rank
     ns, nfull = min(256, nq // max(args.sharded_groups, 1)), 2
-    mine = reference_sample(args, idx, np.concatenate([Qall[-1][rank * nq:rank * nq + ns]] * 1), 1, ns, ns, nfull)
+    mine = reference_sample(args, idx, Qall[-1][(rank + 1) * nq - ns:(rank + 1) * nq], 1, ns, ns, nfull)
     ref = {"scored": {rank: mine["scored"][0]}, "pops": {rank: mine["pops"][0]}, "nbr": {rank: mine["nbr"][0]},
            "lists": {(rank, i): mine["lists"][(0, i)] for i in range(nfull)}}
     rows = n // world
@@ -547,7 +558,7 @@ def sharded_report(args, grp, sh, n, world):
         "evals_per_s": float(tot[1]) / el, "traversals_per_gpu_per_step": args.sharded_nq, "groups_per_gpu": sh["groups"],
         "frontier_steps_per_step": sh["steps"] / max(args.sh_steps, 1),
         "exchanged_bytes_per_rank_per_step": sh["bytes"] / max(args.sh_steps, 1),
-        "request_slots_per_traversal_per_step": sh["width"], "engine": sh["engine"],
+        "request_slots_per_traversal_per_step": sh["width"], "engine": sh["engine"], "slots_per_gpu": sh["slots"],
         "speculation": {"depth": sh["spec_depth"], "scores_requested": int(tot[4]), "scores_used": int(tot[5]),
                         "expansions_finished_from_them": int(tot[6]),
                         "wasted_evaluations": int(tot[4] - tot[5]),

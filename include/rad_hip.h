@@ -356,6 +356,11 @@ int radhip_shard_speculation(const radhip_shard_t *s, uint32_t *out_depth, uint6
  * per traversal and step (RADHIP_NO_SLOT padded; the widest adjacency row, times 1 + the speculation depth); scores
  * are and | or << 16. */
 uint32_t radhip_shard_width(const radhip_shard_t *s);
+/* Slots of this shard: the queue and the sets of a traversal (3.6 MB at n_to_score = 100k) exist once per slot, and a slot
+ * whose traversal is done takes the next one of the batch.  nq by default (one slot per traversal); RADHIP_SHARD_SLOTS=N at
+ * create gives the row engine N < nq slots (radhip_shard_run only: the host-staged pieces below need one slot per
+ * traversal).  Results, statistics and pop logs are by traversal number either way. */
+uint32_t radhip_shard_slots(const radhip_shard_t *s);
 /* which step kernel drives the local traversals (RADHIP_SHARD_ENGINE = row | thread | wave, read at create):
  * 2 = "row" (the default: sixteen lanes per traversal, a 16-ary heap whose levels are 128-B lines, neighbours probed
  * one per lane; state in HBM), 0 = "thread" (one thread per traversal, 8-ary heap; also the fallback for queues of

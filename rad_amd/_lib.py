@@ -118,6 +118,7 @@ SIGNATURES = {
     "radhip_shard_reset": (C.c_int, [_P, _P]),
     "radhip_shard_run": (C.c_int, [_P, _P, _U64, C.POINTER(_U64)]),
     "radhip_shard_width": (_U32, [_P]),
+    "radhip_shard_slots": (_U32, [_P]),
     "radhip_shard_engine": (C.c_int, [_P]),
     "radhip_shard_step": (C.c_int, [_P, C.POINTER(_U32)]),
     "radhip_shard_get_requests": (C.c_int, [_P, _P]),

@@ -55,9 +55,14 @@ struct ShardHeader {
     // the speculative expansions of the last step: queue head s was node spec_node[s] on level spec_level[s]; its
     // unscored neighbours are the spec_cnt[s] candidates from req[W + spec_off[s]] on, in row order
     uint32_t spec_node[2];
-    uint8_t spec_level[2], spec_cnt[2], spec_off[2], pad_[2];
+    uint8_t spec_level[2], spec_cnt[2], spec_off[2], no_more, pad_;   // no_more: the batch had no traversal left when this slot asked (row engine)
     uint64_t spec_req, spec_hit, spec_used;   // statistics: speculative scores asked for / expansions finished from them / scores used
+    // row engine: the traversal this slot works on (+ 1; 0 = none yet) and the epoch its set entries carry — a slot that is
+    // done takes the next traversal of the batch (P.next_t) and leaves the last one's entries behind as stale
+    uint32_t tid1, epoch;
 };
+// what a traversal has to show, by traversal number (a slot writes it at the end of every step: the slot moves on)
+struct ShardResult { uint64_t n_scored, n_pops, n_nbr; int32_t status; uint32_t n_vis; };
 
 struct ShardParams {
     const uint32_t *adj0, *upper_row, *adjU, *top;
@@ -76,6 +81,9 @@ struct ShardParams {
     const uint32_t *scores_in;   // [nq * Wt]: and | or << 16 of the previous step's candidates
     uint32_t *poplog_nodes; uint8_t *poplog_levels; uint64_t poplog_cap;
     uint32_t max_inner;          // pops per step at most while nothing needs a score
+    uint32_t ns;                 // slots (<= nq): heap / sets / request rows exist per SLOT, scored lists / pop logs / results per traversal
+    uint32_t *next_t;            // row engine: traversals taken beyond the first of every slot (the next one is ns + *next_t)
+    ShardResult *res;            // [nq]
 };
 // the live word behind a rank's candidates: live traversals in bits 0..30, bit 31 = a traversal of this rank
 // failed on the device (every rank sees it in the all-gather and the loop ends everywhere at the same step)
@@ -181,7 +189,8 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
     if (q >= P.nq) return;
     ShardHeader H = P.hdr[q];
     uint32_t *req = P.req + (uint64_t)q * P.Wt;
-    uint32_t *live = P.req + (uint64_t)P.nq * P.Wt;
+    uint32_t *live = P.req + (uint64_t)P.ns * P.Wt + P.ns;     // (thread engine: one slot per traversal, ns == nq)
+    P.req[(uint64_t)P.ns * P.Wt + q] = q;
     if (H.status != 0) {
         if (H.n_pend || H.n_spec) { for (uint32_t i = 0; i < P.Wt; ++i) req[i] = RADHIP_NO_SLOT; H.n_pend = 0; H.n_spec = 0; P.hdr[q] = H; }
         if (H.status < 0) atomicOr(live, SH_POISON);
@@ -463,6 +472,7 @@ __global__ __launch_bounds__(64) void shard_step_kernel(ShardParams P) {
     else for (uint32_t i = (k > P.W ? k : P.W); i < P.Wt; ++i) req[i] = RADHIP_NO_SLOT;
     H.n_spec = ns;
     P.hdr[q] = H;
+    { ShardResult R; R.n_scored = H.n_scored; R.n_pops = H.n_pops; R.n_nbr = H.n_nbr; R.status = H.status; R.n_vis = H.n_vis; P.res[q] = R; }
     if (H.status == 0) atomicAdd(live, 1u);   // live traversals of this rank
     else if (H.status < 0) atomicOr(live, SH_POISON);
 }
@@ -531,14 +541,24 @@ __device__ __forceinline__ unsigned long long shr_pop(unsigned long long *h, uin
     if (gl == 0) shr_st(&h[SHR_AT(i)], last);
     return top;
 }
+// Set entries of the row engine carry the slot's epoch (scored set: bits 57..63, visited set: bits 40..46): what an earlier
+// traversal of the slot left behind reads as empty.
+#define SHR_SC_EPOCH_SHIFT 57
+#define SHR_VIS_EPOCH_SHIFT 40
+__device__ __forceinline__ bool shr_sc_free(unsigned long long e, uint32_t epoch) { return e == SH_EMPTY64 || (uint32_t)(e >> SHR_SC_EPOCH_SHIFT) != epoch; }
+__device__ __forceinline__ bool shr_vis_free(unsigned long long e, uint32_t epoch) { return e == SH_EMPTY64 || (uint32_t)(e >> SHR_VIS_EPOCH_SHIFT) != epoch; }
 // true if (slot, level) was already in the set, else inserts it: ONE lane per key, distinct keys per call site
-__device__ __forceinline__ bool shr_vis_tas(unsigned long long *vis, uint64_t vmask, uint32_t slot, uint32_t level) {
-    const unsigned long long k1 = (((unsigned long long)slot << 4) | level) + 1ull;
-    uint64_t i = sh_h64(k1) & vmask;
+__device__ __forceinline__ bool shr_vis_tas(unsigned long long *vis, uint64_t vmask, uint32_t slot, uint32_t level, uint32_t epoch) {
+    const unsigned long long body = (((unsigned long long)slot << 4) | level) + 1ull;
+    const unsigned long long k1 = body | ((unsigned long long)epoch << SHR_VIS_EPOCH_SHIFT);
+    uint64_t i = sh_h64(body) & vmask;
+    unsigned long long expect = SH_EMPTY64;             // (one round trip where the bucket was never used: the common case)
     for (;;) {
-        const unsigned long long old = atomicCAS(&vis[i], SH_EMPTY64, k1);
-        if (old == SH_EMPTY64) return false;
-        if (old == k1) return true;
+        const unsigned long long cur = atomicCAS(&vis[i], expect, k1);
+        if (cur == expect) return false;                // inserted
+        if (cur == k1) return true;
+        if (shr_vis_free(cur, epoch)) { expect = cur; continue; }   // a stale entry (or another lane's fresh one: looked at again)
+        expect = SH_EMPTY64;
         i = (i + 1) & vmask;
     }
 }
@@ -549,24 +569,42 @@ __global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
     __shared__ ShardRowLds L;
     const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15u, gshift = g * 16u;
     const uint32_t lt = (1u << gl) - 1u;
-    const uint32_t q = blockIdx.x * 4u + g;
-    if (q >= P.nq) return;                 // (whole rows leave: everything below is row-uniform control flow)
+    const uint32_t q = blockIdx.x * 4u + g;   // the SLOT: heap, sets, request row
+    if (q >= P.ns) return;                    // (whole rows leave: everything below is row-uniform control flow)
     ShardHeader H = P.hdr[q];
     uint32_t *req = P.req + (uint64_t)q * P.Wt;
-    uint32_t *live = P.req + (uint64_t)P.nq * P.Wt;
-    if (H.status != 0) {
+    uint32_t *tidw = P.req + (uint64_t)P.ns * P.Wt + q;         // which traversal's query the owners score this slot's candidates against
+    uint32_t *live = P.req + (uint64_t)P.ns * P.Wt + P.ns;
+    if (H.tid1 == 0u || H.status != 0) {
+        // nothing to work on: the slot's traversal is done (its results are in P.res), or this is the first step
         if (H.n_pend || H.n_spec) {
             for (uint32_t i = gl; i < P.Wt; i += 16u) req[i] = RADHIP_NO_SLOT;
             H.n_pend = 0; H.n_spec = 0;
-            if (gl == 0) P.hdr[q] = H;
         }
-        if (H.status < 0 && gl == 0) atomicOr(live, SH_POISON);
-        return;
+        uint32_t t = 0xFFFFFFFFu;
+        if (H.tid1 == 0u) t = q;                 // the first traversal of slot s is traversal s (what the host-staged exchange assumes)
+        else if (H.status >= 0 && H.epoch < 127u && !H.no_more) {   // (a failed traversal keeps its slot: the error stays visible)
+            if (gl == 0) t = P.ns + atomicAdd(P.next_t, 1u);
+            t = (uint32_t)__shfl((int)t, 0, 16);
+        }
+        if (t >= P.nq) {
+            // (asked once: thousands of finished slots adding to one counter at every step cost more than the step)
+            const bool first_no = !H.no_more;
+            H.no_more = 1;
+            if (gl == 0) { if (first_no || H.status < 0) P.hdr[q] = H; if (H.status < 0) atomicOr(live, SH_POISON); }
+            return;
+        }
+        // take traversal t: an empty queue, sets whose old entries are stale, the entry points still to come
+        H.n_scored = 0; H.n_pops = 0; H.n_nbr = 0; H.heap_n = 0; H.prime_at = 0; H.pend_level = 0; H.status = 0; H.n_vis = 0;
+        H.spec_cnt[0] = H.spec_cnt[1] = 0;
+        H.tid1 = t + 1u; H.epoch += 1u; H.no_more = 0;
     }
+    const uint32_t tid = H.tid1 - 1u, epoch = H.epoch;
+    if (gl == 0) *tidw = tid;
     unsigned long long *heap = P.heap + (uint64_t)q * P.heap_stride;
     unsigned long long *vis = P.vis + ((uint64_t)q << P.vlog2);
     unsigned long long *sc = P.sc + ((uint64_t)q << P.slog2);
-    uint2 *scored = P.scored + (uint64_t)q * P.scored_cap;
+    uint2 *scored = P.scored + (uint64_t)tid * P.scored_cap;
     const uint32_t *sin = P.scores_in + (uint64_t)q * P.Wt;
     const uint64_t vmask = (1ull << P.vlog2) - 1ull, smask = (1ull << P.slog2) - 1ull;
     const uint32_t vis_limit = (uint32_t)(((1ull << P.vlog2) / 4ull) * 3ull);
@@ -577,9 +615,17 @@ __global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
         const bool on = gl < n;
         if (on) {
             scored[H.n_scored + gl] = make_uint2(slot, v);
-            const unsigned long long e = (unsigned long long)(slot + 1u) | ((unsigned long long)(sh_pack(v) | (level == 0u ? SH_V0 : 0u)) << 32);
+            const unsigned long long e = (unsigned long long)(slot + 1u) | ((unsigned long long)(sh_pack(v) | (level == 0u ? SH_V0 : 0u)) << 32) |
+                                         ((unsigned long long)epoch << SHR_SC_EPOCH_SHIFT);
             uint64_t bi = sh_h64((uint64_t)slot + 1ull) & smask;
-            while (atomicCAS(&sc[bi], SH_EMPTY64, e) != SH_EMPTY64) bi = (bi + 1) & smask;
+            unsigned long long expect = SH_EMPTY64;     // (one round trip where the bucket was never used: the common case)
+            for (;;) {
+                const unsigned long long cur = atomicCAS(&sc[bi], expect, e);
+                if (cur == expect) break;
+                if (shr_sc_free(cur, epoch)) { expect = cur; continue; }
+                expect = SH_EMPTY64;
+                bi = (bi + 1) & smask;
+            }
         }
         H.n_scored += n;
         const unsigned long long key = rh_make_key_dev(rh_q24_dev(v & 0xFFFFu, v >> 16), slot, level);
@@ -603,7 +649,7 @@ __global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
             bool ins = false;
             if (i < cnt) {
                 const uint32_t slot = P.top[H.prime_at + i];
-                if (P.start_level > 0) ins = !shr_vis_tas(vis, vmask, slot, (uint32_t)P.start_level);
+                if (P.start_level > 0) ins = !shr_vis_tas(vis, vmask, slot, (uint32_t)P.start_level, epoch);
                 req[i] = slot;
             }
             H.n_vis += (uint32_t)__popc(shr_ballot(ins, gshift));
@@ -621,8 +667,8 @@ __global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
             uint32_t slot, level;
             rh_decode_key(key, &slot, &level);
             if (P.poplog_nodes && H.n_pops < P.poplog_cap && gl == 0) {
-                P.poplog_nodes[(uint64_t)q * P.poplog_cap + H.n_pops] = slot;
-                P.poplog_levels[(uint64_t)q * P.poplog_cap + H.n_pops] = (uint8_t)level;
+                P.poplog_nodes[(uint64_t)tid * P.poplog_cap + H.n_pops] = slot;
+                P.poplog_levels[(uint64_t)tid * P.poplog_cap + H.n_pops] = (uint8_t)level;
             }
             H.n_pops++;
             const uint32_t cap = level == 0 ? P.cap0 : P.capU;
@@ -638,7 +684,7 @@ __global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
                 bool go = gl < cnt16;
                 if (level > 0u) {            // visited test-and-set on an upper level: the small set
                     bool ins = false;
-                    if (go) { const bool seen = shr_vis_tas(vis, vmask, nb, level); ins = !seen; go = !seen; }
+                    if (go) { const bool seen = shr_vis_tas(vis, vmask, nb, level, epoch); ins = !seen; go = !seen; }
                     H.n_vis += (uint32_t)__popc(shr_ballot(ins, gshift));
                 }
                 bool found = false;
@@ -649,7 +695,7 @@ __global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
                     si = sh_h64((uint64_t)nb + 1ull) & smask;
                     for (;;) {
                         se = shr_ld(&sc[si]);
-                        if (se == SH_EMPTY64) break;
+                        if (shr_sc_free(se, epoch)) break;
                         if ((uint32_t)se == nb + 1u) { found = true; v = (uint32_t)(se >> 32); break; }
                         si = (si + 1) & smask;
                     }
@@ -707,12 +753,12 @@ __global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
                 const uint32_t nl = level - 1u;
                 uint32_t fresh = 0u;
                 if (gl == 0) {
-                    if (nl > 0u) fresh = shr_vis_tas(vis, vmask, slot, nl) ? 0u : 1u;
+                    if (nl > 0u) fresh = shr_vis_tas(vis, vmask, slot, nl, epoch) ? 0u : 1u;
                     else {   // the node is scored, hence in the scored set: visited(node, 0) is its v0 bit
                         uint64_t si = sh_h64((uint64_t)slot + 1ull) & smask;
                         for (uint64_t tries = 0; tries <= smask; ++tries) {
                             const unsigned long long se = shr_ld(&sc[si]);
-                            if (se == SH_EMPTY64) break;   // (unreachable by construction)
+                            if (shr_sc_free(se, epoch)) break;   // (unreachable by construction)
                             if ((uint32_t)se == slot + 1u) {
                                 if (!((uint32_t)(se >> 32) & SH_V0)) { shr_st(&sc[si], se | ((unsigned long long)SH_V0 << 32)); fresh = 1u; }
                                 break;
@@ -761,7 +807,7 @@ __global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
                     unscored = true;
                     for (;;) {
                         const unsigned long long se = shr_ld(&sc[si]);
-                        if (se == SH_EMPTY64) break;
+                        if (shr_sc_free(se, epoch)) break;
                         if ((uint32_t)se == nb + 1u) { unscored = false; break; }
                         si = (si + 1) & smask;
                     }
@@ -782,7 +828,11 @@ __global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
     H.n_spec = ns;
     if (gl == 0) {
         P.hdr[q] = H;
-        if (H.status == 0) atomicAdd(live, 1u);   // live traversals of this rank
+        ShardResult R; R.n_scored = H.n_scored; R.n_pops = H.n_pops; R.n_nbr = H.n_nbr; R.status = H.status; R.n_vis = H.n_vis;
+        P.res[tid] = R;
+        // live = traversals of this rank still to finish: this one if it runs on, or (if it is done) the slot will try to take
+        // another one at the next step — it counts as live while the batch has any left
+        if (H.status == 0 || (H.status > 0 && P.ns + shr_ld32(P.next_t) < P.nq)) atomicAdd(live, 1u);
         else if (H.status < 0) atomicOr(live, SH_POISON);
     }
 }
@@ -793,31 +843,35 @@ struct EvalParams {
     uint64_t first, count;
     const uint4 *queries;        // [world * nq] query rows (padded to the row stride)
     const uint32_t *qpop;        // [world * nq]
-    const uint32_t *req_all;     // [world][nq * W + 16]
-    uint32_t *out;               // [world][nq * W]
-    uint32_t *live;              // this rank's live count (behind its own candidates): zeroed here for the next step
-    uint32_t world, nq, W;
+    const uint32_t *req_all;     // [world][ns * W candidates | ns traversal numbers | 16 (live word first)]
+    uint32_t *out;               // [world][ns * W]
+    uint32_t *live;              // this rank's live count (behind its own block): zeroed here for the next step
+    uint32_t world, nq, W;       // nq = traversals per rank (rows of `queries` per rank)
+    uint32_t ns;                 // slots per rank
+    uint32_t identity;           // 1: slot s works on traversal s (host-staged exchange: the traversal numbers do not travel)
 };
 
 template <int LPR>
 __global__ __launch_bounds__(256) void shard_eval_kernel(EvalParams P) {
     constexpr int GPW = 64 / LPR, U = 4;
     const uint32_t lane = threadIdx.x & 63u, chunk = lane % LPR, grp = lane / LPR;
-    const uint64_t per_rank = (uint64_t)P.nq * P.W, total = per_rank * P.world;
+    const uint64_t per_rank = (uint64_t)P.ns * P.W, total = per_rank * P.world, blk = per_rank + P.ns + 16u;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     if (blockIdx.x == 0 && threadIdx.x == 0) *P.live = 0u;   // (the all-gather before this kernel has taken it)
     for (uint64_t base = wave * (GPW * U); base < total; base += n_waves * (GPW * U)) {
-        uint32_t sl[U];
+        uint32_t sl[U], tr[U];
         uint64_t at[U];
         uint4 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             at[u] = base + (uint64_t)u * GPW + grp;
-            sl[u] = RADHIP_NO_SLOT;
+            sl[u] = RADHIP_NO_SLOT; tr[u] = 0u;
             if (at[u] < total) {
-                const uint64_t r = at[u] / per_rank, off = at[u] - r * per_rank;
-                sl[u] = P.req_all[r * (per_rank + 16u) + off];
+                const uint32_t r = (uint32_t)(at[u] / per_rank), off = (uint32_t)(at[u] - (uint64_t)r * per_rank), sslot = off / P.W;
+                sl[u] = P.req_all[(uint64_t)r * blk + off];
+                // rank * nq + the traversal the asking slot works on (it travels behind the candidates; loaded beside them)
+                tr[u] = r * P.nq + (P.identity ? sslot : P.req_all[(uint64_t)r * blk + per_rank + sslot]);
             }
             const bool mine = sl[u] != RADHIP_NO_SLOT && sl[u] >= P.first && sl[u] < P.first + P.count;
             v[u] = make_uint4(0, 0, 0, 0);
@@ -828,7 +882,7 @@ __global__ __launch_bounds__(256) void shard_eval_kernel(EvalParams P) {
         for (int u = 0; u < U; ++u) {
             uint32_t res = 0u;
             if (sl[u] != RADHIP_NO_SLOT) {
-                const uint64_t tq = at[u] / P.W;              // global traversal number = rank * nq + q
+                const uint64_t tq = tr[u];
                 const uint4 qv = P.queries[tq * LPR + chunk];
                 const uint32_t rp = rh_group_sum<LPR>(rh_popc4(v[u]));
                 const uint32_t a = rh_group_sum<LPR>(rh_popc4_and(v[u], qv));
@@ -846,6 +900,7 @@ struct radhip_shard {
     radhip_index *idx = nullptr;
     int rank = 0, world = 1;
     uint32_t nq = 0, W = 0;       // W = request slots per traversal and step (row width x (1 + spec))
+    uint32_t ns = 0;              // slots (== nq unless the row engine was given fewer: RADHIP_SHARD_SLOTS)
     uint32_t Wrow = 0, spec = 0;
     hipStream_t stream = nullptr; // the stream this shard's kernels and collectives run on (the index's, or its own: pairs)
     bool own_stream = false;
@@ -870,7 +925,7 @@ extern "C" int radhip_shard_destroy(radhip_shard_t *s) {
     if (s->wave) (void)radhip_traversal_destroy(s->wave);
     if (s->idx && s->idx->dev_ready) (void)hipSetDevice(s->idx->device);
     void *ps[] = {s->d_queries, s->d_qpop, s->d_req, s->d_req_all, s->d_out, s->d_in, s->P.hdr, s->P.heap, s->P.vis, s->P.sc,
-                  s->P.scored, s->P.poplog_nodes, s->P.poplog_levels};
+                  s->P.scored, s->P.poplog_nodes, s->P.poplog_levels, s->P.next_t, s->P.res};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -953,8 +1008,15 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     // makes every step as slow as the unluckiest of thousands of traversals (measured: 2 beats 1, 4 and 8)
     P.max_inner = 2;
     if (const char *e = getenv("RADHIP_SHARD_INNER")) { const int v = atoi(e); if (v >= 1 && v <= 64) P.max_inner = (uint32_t)v; }
+    // Slots: the heavy per-traversal structures (queue, sets: 3.6 MB at n_to_score = 100k) exist once per SLOT; a batch may
+    // hold more traversals than slots (RADHIP_SHARD_SLOTS, row engine, product loop): a slot whose traversal is done takes
+    // the next one.  The traversals of a batch differ in length (the longest needs twice the mean) and the loop runs until
+    // the last one ends: with one slot per traversal half of the slot-steps of a batch are idle.
+    uint32_t ns = nq;
+    if (const char *e = getenv("RADHIP_SHARD_SLOTS")) { const long long v = atoll(e); if (v > 0 && (uint64_t)v < nq && s->row) ns = (uint32_t)v; }
+    s->ns = ns; P.ns = ns;
     int rc = RADHIP_OK;
-    const size_t per_rank = (size_t)nq * W;
+    const size_t per_rank = (size_t)ns * W;
     auto al = [&](void **p, size_t bytes, bool zero) {
         if (rc != RADHIP_OK) return;
         hipError_t e = hipMalloc(p, bytes ? bytes : 16);
@@ -968,14 +1030,16 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
         if (zero && hipMemsetAsync(*p, 0, bytes ? bytes : 16, idx->stream) != hipSuccess) rc = RADHIP_E_HIP;
     };
     if (!wave) {
-        al((void **)&P.hdr, (size_t)nq * sizeof(ShardHeader), true);
-        al((void **)&P.heap, (size_t)nq * P.heap_stride * 8, false);
-        al((void **)&P.vis, ((size_t)nq << vlog2) * 8, true);
-        al((void **)&P.sc, ((size_t)nq << slog2) * 8, true);
+        al((void **)&P.hdr, (size_t)ns * sizeof(ShardHeader), true);
+        al((void **)&P.heap, (size_t)ns * P.heap_stride * 8, false);
+        al((void **)&P.vis, ((size_t)ns << vlog2) * 8, true);
+        al((void **)&P.sc, ((size_t)ns << slog2) * 8, true);
         al((void **)&P.scored, (size_t)nq * scored_cap * sizeof(uint2), false);
+        al((void **)&P.res, (size_t)nq * sizeof(ShardResult), true);
+        al((void **)&P.next_t, 64, true);
     } else s->state_bytes += radhip_traversal_state_bytes(wave);
-    al((void **)&s->d_req, (per_rank + 16) * 4, true);
-    al((void **)&s->d_req_all, (size_t)world * (per_rank + 16) * 4, true);
+    al((void **)&s->d_req, (per_rank + ns + 16) * 4, true);
+    al((void **)&s->d_req_all, (size_t)world * (per_rank + ns + 16) * 4, true);
     al((void **)&s->d_out, (size_t)world * per_rank * 4, true);
     al((void **)&s->d_in, per_rank * 4, true);
     al((void **)&s->d_queries, (size_t)world * nq * idx->row_stride, false);
@@ -1009,7 +1073,8 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     EvalParams &E = s->E;
     E.fp = idx->d_fp + (row_first - idx->shard_first) * idx->lpr;
     E.first = row_first; E.count = row_count; E.queries = s->d_queries; E.qpop = s->d_qpop;
-    E.req_all = s->d_req_all; E.out = s->d_out; E.live = s->d_req + per_rank; E.world = (uint32_t)world; E.nq = nq; E.W = W;
+    E.req_all = s->d_req_all; E.out = s->d_out; E.live = s->d_req + per_rank + ns; E.world = (uint32_t)world; E.nq = nq; E.W = W;
+    E.ns = ns; E.identity = 0;
     *out = s;
     return RADHIP_OK;
 }
@@ -1024,7 +1089,7 @@ extern "C" int radhip_shard_reset(radhip_shard_t *s, const uint8_t *queries_all)
     if (s->graph_gen != idx->graph_gen)
         RH_FAIL(RADHIP_E_STATE, "the index changed since this sharded traversal was created: create a new one");
     RH_HIP(hipSetDevice(idx->device));
-    const size_t tq = (size_t)s->world * s->nq, per_rank = (size_t)s->nq * s->W;
+    const size_t tq = (size_t)s->world * s->nq, per_rank = (size_t)s->ns * s->W;
     std::vector<uint8_t> padded(tq * idx->row_stride, 0);
     std::vector<uint32_t> pop(tq, 0);
     for (size_t i = 0; i < tq; ++i) {
@@ -1037,11 +1102,13 @@ extern "C" int radhip_shard_reset(radhip_shard_t *s, const uint8_t *queries_all)
     RH_HIP(hipMemcpyAsync(s->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, st));
     RH_HIP(hipMemcpyAsync(s->d_qpop, pop.data(), tq * 4, hipMemcpyHostToDevice, st));
     if (!s->wave) {
-        RH_HIP(hipMemsetAsync(s->P.hdr, 0, (size_t)s->nq * sizeof(ShardHeader), st));
-        RH_HIP(hipMemsetAsync(s->P.vis, 0, ((size_t)s->nq << s->P.vlog2) * 8, st));
-        RH_HIP(hipMemsetAsync(s->P.sc, 0, ((size_t)s->nq << s->P.slog2) * 8, st));
+        RH_HIP(hipMemsetAsync(s->P.hdr, 0, (size_t)s->ns * sizeof(ShardHeader), st));
+        RH_HIP(hipMemsetAsync(s->P.vis, 0, ((size_t)s->ns << s->P.vlog2) * 8, st));
+        RH_HIP(hipMemsetAsync(s->P.sc, 0, ((size_t)s->ns << s->P.slog2) * 8, st));
+        RH_HIP(hipMemsetAsync(s->P.res, 0, (size_t)s->nq * sizeof(ShardResult), st));
+        RH_HIP(hipMemsetAsync(s->P.next_t, 0, 64, st));
     }
-    RH_HIP(hipMemsetAsync(s->d_req, 0, (per_rank + 16) * 4, st));
+    RH_HIP(hipMemsetAsync(s->d_req, 0, (per_rank + s->ns + 16) * 4, st));
     RH_HIP(hipMemsetAsync(s->d_in, 0, per_rank * 4, st));
     RH_HIP(hipStreamSynchronize(st));
     s->step_ms = 0.0; s->eval_ms = 0.0; s->steps = 0; s->exchanged_bytes = 0;
@@ -1049,6 +1116,7 @@ extern "C" int radhip_shard_reset(radhip_shard_t *s, const uint8_t *queries_all)
 }
 
 extern "C" uint32_t radhip_shard_width(const radhip_shard_t *s) { return s ? s->W : 0; }
+extern "C" uint32_t radhip_shard_slots(const radhip_shard_t *s) { return s ? s->ns : 0; }
 extern "C" int radhip_shard_speculation(const radhip_shard_t *s, uint32_t *out_depth, uint64_t *out_requested, uint64_t *out_used,
                                         uint64_t *out_hits) {
     if (!s) RH_FAIL(RADHIP_E_INVALID, "null argument");
@@ -1057,9 +1125,9 @@ extern "C" int radhip_shard_speculation(const radhip_shard_t *s, uint32_t *out_d
     if (!s->wave && s->spec) {
         std::lock_guard<std::mutex> lk(s->idx->mu);
         RH_HIP(hipSetDevice(s->idx->device));
-        std::vector<ShardHeader> hdr(s->nq);
-        RH_HIP(hipMemcpy(hdr.data(), s->P.hdr, (size_t)s->nq * sizeof(ShardHeader), hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < s->nq; ++i) { rq += hdr[i].spec_req; us += hdr[i].spec_used; hi += hdr[i].spec_hit; }
+        std::vector<ShardHeader> hdr(s->ns);
+        RH_HIP(hipMemcpy(hdr.data(), s->P.hdr, (size_t)s->ns * sizeof(ShardHeader), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < s->ns; ++i) { rq += hdr[i].spec_req; us += hdr[i].spec_used; hi += hdr[i].spec_hit; }
     }
     if (out_requested) *out_requested = rq;
     if (out_used) *out_used = us;
@@ -1079,9 +1147,9 @@ static int shard_check(radhip_shard *s) {
 // enqueue one step kernel on the shard's stream (no synchronisation)
 static int shard_enqueue_step(radhip_shard *s, bool zero_live) {
     // (in the product loop the evaluation kernel of the step before has zeroed the live count: one launch less)
-    if (zero_live) RH_HIP(hipMemsetAsync(s->d_req + (size_t)s->nq * s->W, 0, 64, s->stream));
+    if (zero_live) RH_HIP(hipMemsetAsync(s->d_req + (size_t)s->ns * s->W + s->ns, 0, 64, s->stream));
     if (s->wave) return rh_trav_enqueue_shard_step(s->wave);
-    if (s->row) hipLaunchKernelGGL(shard_step_row_kernel, dim3((s->nq + 3u) / 4u), dim3(64), 0, s->stream, s->P);
+    if (s->row) hipLaunchKernelGGL(shard_step_row_kernel, dim3((s->ns + 3u) / 4u), dim3(64), 0, s->stream, s->P);
     else hipLaunchKernelGGL(shard_step_kernel, dim3((s->nq + 63u) / 64u), dim3(64), 0, s->stream, s->P);
     RH_HIP(hipGetLastError());
     return RADHIP_OK;
@@ -1089,7 +1157,7 @@ static int shard_enqueue_step(radhip_shard *s, bool zero_live) {
 static int shard_enqueue_eval(radhip_shard *s) {
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->idx->device);
-    const uint64_t total = (uint64_t)s->world * s->nq * s->W;
+    const uint64_t total = (uint64_t)s->world * s->ns * s->W;
     const uint64_t per_block = 4ull * (64 / s->idx->lpr) * 4ull;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((total + per_block - 1) / per_block, (uint64_t)n_cu * 8));
     switch (s->idx->lpr) {
@@ -1104,15 +1172,18 @@ static int shard_enqueue_eval(radhip_shard *s) {
 }
 
 // ---- host-staged pieces (tests, rehearsal on one GPU, any exchange the host program has) -------------
+// (the host-staged exchange moves candidates and scores only, not the slots' traversal numbers: one slot per traversal)
+#define SH_REQUIRE_IDENTITY(s) do { if ((s)->ns != (s)->nq) RH_FAIL(RADHIP_E_STATE, "the host-staged exchange needs one slot per traversal (RADHIP_SHARD_SLOTS is for radhip_shard_run)"); } while (0)
 extern "C" int radhip_shard_step(radhip_shard_t *s, uint32_t *out_live) {
     if (!s) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    SH_REQUIRE_IDENTITY(s);
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_TRY(shard_check(s));
     RH_HIP(hipEventRecord(s->ev0, s->stream));
     RH_TRY(shard_enqueue_step(s, true));
     RH_HIP(hipEventRecord(s->ev1, s->stream));
     uint32_t live = 0;
-    RH_HIP(hipMemcpyAsync(&live, s->d_req + (size_t)s->nq * s->W, 4, hipMemcpyDeviceToHost, s->stream));
+    RH_HIP(hipMemcpyAsync(&live, s->d_req + (size_t)s->ns * s->W + s->ns, 4, hipMemcpyDeviceToHost, s->stream));
     RH_HIP(hipStreamSynchronize(s->stream));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->step_ms += ms;
@@ -1123,6 +1194,7 @@ extern "C" int radhip_shard_step(radhip_shard_t *s, uint32_t *out_live) {
 }
 extern "C" int radhip_shard_get_requests(radhip_shard_t *s, uint32_t *host) {
     if (!s || !host) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    SH_REQUIRE_IDENTITY(s);
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_TRY(shard_check(s));
     RH_HIP(hipMemcpy(host, s->d_req, (size_t)s->nq * s->W * 4, hipMemcpyDeviceToHost));
@@ -1132,15 +1204,18 @@ extern "C" int radhip_shard_set_requests_all(radhip_shard_t *s, const uint32_t *
     if (!s || !host_all) RH_FAIL(RADHIP_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_TRY(shard_check(s));
+    SH_REQUIRE_IDENTITY(s);
     const size_t per_rank = (size_t)s->nq * s->W;
     for (int r = 0; r < s->world; ++r)
-        RH_HIP(hipMemcpy(s->d_req_all + (size_t)r * (per_rank + 16), host_all + (size_t)r * per_rank, per_rank * 4, hipMemcpyHostToDevice));
+        RH_HIP(hipMemcpy(s->d_req_all + (size_t)r * (per_rank + s->ns + 16), host_all + (size_t)r * per_rank, per_rank * 4, hipMemcpyHostToDevice));
     return RADHIP_OK;
 }
 extern "C" int radhip_shard_evaluate(radhip_shard_t *s) {
     if (!s) RH_FAIL(RADHIP_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_TRY(shard_check(s));
+    SH_REQUIRE_IDENTITY(s);
+    s->E.identity = 1u;
     RH_HIP(hipEventRecord(s->ev0, s->stream));
     RH_TRY(shard_enqueue_eval(s));
     RH_HIP(hipEventRecord(s->ev1, s->stream));
@@ -1151,6 +1226,7 @@ extern "C" int radhip_shard_evaluate(radhip_shard_t *s) {
 }
 extern "C" int radhip_shard_get_scores_out(radhip_shard_t *s, uint32_t *host) {
     if (!s || !host) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    SH_REQUIRE_IDENTITY(s);
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_TRY(shard_check(s));
     RH_HIP(hipMemcpy(host, s->d_out, (size_t)s->world * s->nq * s->W * 4, hipMemcpyDeviceToHost));
@@ -1158,6 +1234,7 @@ extern "C" int radhip_shard_get_scores_out(radhip_shard_t *s, uint32_t *host) {
 }
 extern "C" int radhip_shard_set_scores_in(radhip_shard_t *s, const uint32_t *host) {
     if (!s || !host) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    SH_REQUIRE_IDENTITY(s);
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_TRY(shard_check(s));
     RH_HIP(hipMemcpy(s->d_in, host, (size_t)s->nq * s->W * 4, hipMemcpyHostToDevice));
@@ -1217,17 +1294,18 @@ static int shard_run_groups(radhip_shard **S, radhip_comm **C, int ng, uint64_t 
             for (int g = 0; g < ng; ++g) {
                 radhip_shard *s = S[g];
                 hipStream_t st = s->stream;
-                const size_t per_rank = (size_t)s->nq * s->W;
+                const size_t per_rank = (size_t)s->ns * s->W, blk = per_rank + s->ns + 16;
+                s->E.identity = 0u;
                 if (phases) (void)hipEventRecord(pe[0], st);
                 RH_TRY(shard_enqueue_step(s, steps == 0));
                 if (phases) (void)hipEventRecord(pe[1], st);
-                RH_TRY(rh_comm_allgather_dev(C[g], s->d_req, s->d_req_all, per_rank + 16, st));
+                RH_TRY(rh_comm_allgather_dev(C[g], s->d_req, s->d_req_all, blk, st));
                 if (phases) (void)hipEventRecord(pe[2], st);
                 RH_TRY(shard_enqueue_eval(s));
                 if (phases) (void)hipEventRecord(pe[3], st);
                 RH_TRY(rh_comm_reduce_scatter_u32_dev(C[g], s->d_out, s->d_in, per_rank, st));
                 if (phases) (void)hipEventRecord(pe[4], st);
-                s->exchanged_bytes += (uint64_t)s->world * (per_rank + 16) * 4 + (uint64_t)s->world * per_rank * 4;
+                s->exchanged_bytes += (uint64_t)s->world * blk * 4 + (uint64_t)s->world * per_rank * 4;
             }
             steps++;
             // The live words of all ranks travel behind the candidates, so every rank sees the same numbers and stops
@@ -1238,9 +1316,9 @@ static int shard_run_groups(radhip_shard **S, radhip_comm **C, int ng, uint64_t 
             const bool look = phases || last || (steps % (steps * S[0]->W < S[0]->n_to_score ? 64u : 4u)) == 0u;
             if (!look) continue;
             for (int g = 0; g < ng; ++g) {
-                const size_t per_rank = (size_t)S[g]->nq * S[g]->W;
+                const size_t per_rank = (size_t)S[g]->ns * S[g]->W, blk = per_rank + S[g]->ns + 16;
                 for (int r = 0; r < world; ++r)
-                    RH_HIP(hipMemcpyAsync(&live[(size_t)g * world + r], S[g]->d_req_all + (size_t)r * (per_rank + 16) + per_rank, 4, hipMemcpyDeviceToHost, S[g]->stream));
+                    RH_HIP(hipMemcpyAsync(&live[(size_t)g * world + r], S[g]->d_req_all + (size_t)r * blk + per_rank + S[g]->ns, 4, hipMemcpyDeviceToHost, S[g]->stream));
             }
             for (int g = 0; g < ng; ++g) RH_TRY(shard_sync(S[g]->stream));
             if (phases) for (int i = 0; i < 4; ++i) { float m = 0.f; if (hipEventElapsedTime(&m, pe[i], pe[i + 1]) == hipSuccess) pms[i] += m; }
@@ -1313,10 +1391,10 @@ static int shard_first_error(radhip_shard *s) {
                                           "RADHIP_SHARD_ENGINE=thread sizes its queue for the whole graph", i, st[i].status);
         return RADHIP_OK;
     }
-    std::vector<ShardHeader> hdr(s->nq);
-    RH_HIP(hipMemcpy(hdr.data(), s->P.hdr, (size_t)s->nq * sizeof(ShardHeader), hipMemcpyDeviceToHost));
+    std::vector<ShardResult> res(s->nq);
+    RH_HIP(hipMemcpy(res.data(), s->P.res, (size_t)s->nq * sizeof(ShardResult), hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < s->nq; ++i)
-        if (hdr[i].status < 0) RH_FAIL(hdr[i].status, "sharded traversal %u overflowed a fixed-capacity device structure (status %d)", i, hdr[i].status);
+        if (res[i].status < 0) RH_FAIL(res[i].status, "sharded traversal %u overflowed a fixed-capacity device structure (status %d)", i, res[i].status);
     return RADHIP_OK;
 }
 
@@ -1325,12 +1403,12 @@ extern "C" int radhip_shard_stats(const radhip_shard_t *s, radhip_trav_stats_t *
     if (s->wave) return radhip_traversal_stats(s->wave, out);
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_HIP(hipSetDevice(s->idx->device));
-    std::vector<ShardHeader> hdr(s->nq);
-    RH_HIP(hipMemcpy(hdr.data(), s->P.hdr, (size_t)s->nq * sizeof(ShardHeader), hipMemcpyDeviceToHost));
+    std::vector<ShardResult> res(s->nq);
+    RH_HIP(hipMemcpy(res.data(), s->P.res, (size_t)s->nq * sizeof(ShardResult), hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < s->nq; ++i) {
-        out[i].n_scored = hdr[i].n_scored; out[i].n_pops = hdr[i].n_pops; out[i].n_nbr = hdr[i].n_nbr;
-        out[i].n_repivot = 0; out[i].n_flush = 0; out[i].status = hdr[i].status; out[i].n_remid = 0;
-        out[i].n_upper = hdr[i].n_vis;
+        out[i].n_scored = res[i].n_scored; out[i].n_pops = res[i].n_pops; out[i].n_nbr = res[i].n_nbr;
+        out[i].n_repivot = 0; out[i].n_flush = 0; out[i].status = res[i].status; out[i].n_remid = 0;
+        out[i].n_upper = res[i].n_vis;
     }
     return RADHIP_OK;
 }
@@ -1342,8 +1420,8 @@ extern "C" int radhip_shard_results(const radhip_shard_t *s, uint32_t q, uint32_
     if (s->wave) return radhip_traversal_results(s->wave, q, out_slots, out_and, out_or, cap, out_n);
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_HIP(hipSetDevice(s->idx->device));
-    ShardHeader h;
-    RH_HIP(hipMemcpy(&h, s->P.hdr + q, sizeof h, hipMemcpyDeviceToHost));
+    ShardResult h;
+    RH_HIP(hipMemcpy(&h, s->P.res + q, sizeof h, hipMemcpyDeviceToHost));
     *out_n = h.n_scored;
     const uint64_t n = std::min<uint64_t>(h.n_scored, cap);
     if (n == 0) return RADHIP_OK;
@@ -1365,8 +1443,8 @@ extern "C" int radhip_shard_pop_log(const radhip_shard_t *s, uint32_t q, uint32_
     if (!s->P.poplog_nodes) RH_FAIL(RADHIP_E_STATE, "sharded traversal was created without RADHIP_TRAV_LOG_POPS");
     std::lock_guard<std::mutex> lk(s->idx->mu);
     RH_HIP(hipSetDevice(s->idx->device));
-    ShardHeader h;
-    RH_HIP(hipMemcpy(&h, s->P.hdr + q, sizeof h, hipMemcpyDeviceToHost));
+    ShardResult h;
+    RH_HIP(hipMemcpy(&h, s->P.res + q, sizeof h, hipMemcpyDeviceToHost));
     const uint64_t m = std::min<uint64_t>(h.n_pops, s->P.poplog_cap);
     *out_n = m;
     const uint64_t n = std::min<uint64_t>(m, cap);

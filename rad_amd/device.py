@@ -345,6 +345,7 @@ class DeviceShard:
         check(self._L.radhip_shard_create(index._h, rank, world, row_first, row_count, ptr(q), self.nq, int(n_to_score),
                                           flags, C.byref(self._h)))
         self.width = int(self._L.radhip_shard_width(self._h))
+        self.slots = int(self._L.radhip_shard_slots(self._h))     # < nq: slots take the traversals of the batch one after the other
         self.engine = {0: "thread", 1: "wave", 2: "row"}[int(self._L.radhip_shard_engine(self._h))]
 
     def close(self):

@@ -330,6 +330,43 @@ def test_link_resident_equals_add(gpu, oracle):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("slots,spec", [(4, "0"), (8, "2"), (5, "1")])
+def test_slots_take_the_traversals_of_a_batch(gpu, oracle, monkeypatch, slots, spec):
+    """RADHIP_SHARD_SLOTS: fewer slots (queue + sets) than traversals; a slot whose traversal is done takes the next one,
+    its sets keep the old entries as stale (epochs).  Results are by traversal number and equal the oracle's."""
+    from rad_amd.device import DeviceShard, RcclComm
+    monkeypatch.setenv("RADHIP_SHARD_ENGINE", "row")
+    monkeypatch.setenv("RADHIP_SHARD_SPEC", spec)
+    monkeypatch.setenv("RADHIP_SHARD_SLOTS", str(slots))
+    n, nq, nts = 30000, 23, 2500
+    X, g, full, Qall = _row_sharded_setup(oracle, n, nts, 1, nq, mode=2, seed=17)
+    comm = RcclComm(0, 1, RcclComm.unique_id(), 0)
+    sh = DeviceShard(full, 0, 1, 0, n, Qall, nts, log_pops=True)
+    assert sh.engine == "row" and sh.slots == slots and sh.nq == nq
+    steps = sh.run(comm)
+    assert steps > 10
+    st = sh.stats()
+    assert set(st.status.tolist()) <= {1, 2}
+    for q in range(nq):
+        want = oracle.rad_traverse(g, X, Qall[q], nts)
+        s_, a, o = sh.results(q)
+        nodes, lv = sh.pop_log(q)
+        assert np.array_equal(s_, want.slots) and np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt), q
+        assert np.array_equal(nodes, want.pop_nodes) and np.array_equal(lv, want.pop_levels), q
+        assert st.n_pops[q] == want.n_pops and st.n_nbr[q] == want.n_nbr
+    # a second batch on the same state
+    Q2 = X[np.random.default_rng(5).integers(0, n, nq)].copy()
+    sh.reset(Q2)
+    sh.run(comm)
+    for q in (0, nq // 2, nq - 1):
+        want = oracle.rad_traverse(g, X, Q2[q], nts)
+        s_, a, o = sh.results(q)
+        assert np.array_equal(s_, want.slots) and np.array_equal(a, want.and_cnt), q
+    with pytest.raises(Exception):
+        sh.step(np.zeros((sh.nq, sh.width), np.uint32))            # the host-staged pieces need one slot per traversal
+    sh.close(); comm.close()
+
+
 @pytest.mark.parametrize("eng", ["row", "thread"])
 def test_speculation_cuts_steps_not_results(gpu, oracle, monkeypatch, eng):
     """Speculative score prefetch: fewer frontier steps, identical committed state."""

@@ -522,6 +522,55 @@ __device__ __forceinline__ void shr_push(unsigned long long *h, uint64_t &n, uns
     if (gl < u) shr_st(&h[SHR_AT(gl == 0 ? i : below)], av);
     if (gl == (u ? u - 1u : 0u)) shr_st(&h[SHR_AT(u ? my : i)], key);
 }
+// The keys of lanes 0 .. n-1 (distinct) enter the heap — one round trip per group of new leaves that share a parent (all of
+// them three times out of four) instead of one per key.  The path from the root to that parent (<= 6 keys, loaded together)
+// and the new keys are ranked against each other in registers: the d smallest go onto the path, top down, the others into
+// the leaves.  A path node only ever receives a key that is not larger than the one it held (the (l+1)-th smallest of the
+// union cannot exceed the (l+1)-th path key), so its other children stay below it; any valid heap pops the same order.
+__device__ __forceinline__ void shr_push_bulk(unsigned long long *h, uint64_t &hn, unsigned long long key, uint32_t n, uint32_t gl, uint32_t gshift) {
+    uint32_t done = 0;
+    while (done < n) {
+        const uint64_t a = hn;                                   // the first free leaf
+        if (a == 0) {                                            // empty heap: the first key is the root
+            const unsigned long long k0 = __shfl(key, (int)done, 16);
+            if (gl == 0) shr_st(&h[SHR_AT(0)], k0);
+            hn = 1; done++;
+            continue;
+        }
+        const uint64_t p = (a - 1) >> 4;
+        const uint64_t room = 16ull * p + 17ull - a;             // leaves a .. 16p + 16 are children of p
+        const uint32_t m = (uint64_t)(n - done) < room ? n - done : (uint32_t)room;
+        // lane l < 6 owns ancestor l of leaf a (l = 0: p)
+        uint64_t an = a, my = ~0ull;
+        bool valid = true;
+#pragma unroll
+        for (uint32_t t = 0; t < 6; ++t) {
+            valid = valid && an > 0;
+            an = valid ? (an - 1) >> 4 : 0;
+            if (t == gl) my = valid ? an : ~0ull;
+        }
+        const unsigned long long cv = my != ~0ull ? shr_ld(&h[SHR_AT(my)]) : RH_KEY_INF;
+        const uint32_t d = (uint32_t)__popc(shr_ballot(my != ~0ull, gshift));
+        const unsigned long long nk_ = __shfl(key, (int)((done + gl) & 15u), 16);                // (every lane of the row shuffles)
+        const unsigned long long nk = gl < m ? nk_ : RH_KEY_INF;
+        uint32_t rn = 0, rc = 0;                                 // rank of this lane's new key / path key in the union
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const unsigned long long kt = __shfl(nk, t, 16);
+            rn += kt < nk ? 1u : 0u; rc += kt < cv ? 1u : 0u;    // (absent keys are INF: they rank behind everything)
+        }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const unsigned long long ct = __shfl(cv, t, 16);
+            rn += ct < nk ? 1u : 0u; rc += ct < cv ? 1u : 0u;
+        }
+        // rank r < d: path position r from the top = ancestor d - 1 - r; r >= d: leaf a + (r - d)
+        const uint64_t pn = __shfl(my, (int)((d - 1u - rn) & 15u), 16), pc = __shfl(my, (int)((d - 1u - rc) & 15u), 16);
+        if (gl < m) shr_st(&h[SHR_AT(rn < d ? pn : a + (rn - d))], nk);
+        if (gl < d && rc != d - 1u - gl) shr_st(&h[SHR_AT(rc < d ? pc : a + (rc - d))], cv);   // (a path key that keeps its place is not rewritten)
+        hn += m; done += m;
+    }
+}
 __device__ __forceinline__ unsigned long long shr_pop(unsigned long long *h, uint64_t &n, uint32_t gl, uint32_t gshift) {
     const unsigned long long top = shr_ld(&h[SHR_AT(0)]);
     const unsigned long long last = shr_ld(&h[SHR_AT(n - 1)]);
@@ -629,7 +678,7 @@ __global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
         }
         H.n_scored += n;
         const unsigned long long key = rh_make_key_dev(rh_q24_dev(v & 0xFFFFu, v >> 16), slot, level);
-        for (uint32_t j = 0; j < n; ++j) shr_push(heap, H.heap_n, __shfl(key, (int)j, 16), gl, gshift);
+        shr_push_bulk(heap, H.heap_n, key, n, gl, gshift);
     };
 
     // ---- finish: the candidates of the last step are scored now

@@ -1056,6 +1056,9 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     // pops per step while nothing needs a score: the step ends with its slowest traversal, so a long inner loop
     // makes every step as slow as the unluckiest of thousands of traversals (measured: 2 beats 1, 4 and 8)
     P.max_inner = 2;
+    // (row engine with slots that stay live: 4 — 270 against 253 M expansions/s and 28.4k against 32.5k steps for 65536
+    // traversals on 32768 slots; 6, 8, 16: 263, 255, 230 M — profiles/r03/sharded_slots/spec_inner_sweep.log)
+    if (s->row) P.max_inner = 4;
     if (const char *e = getenv("RADHIP_SHARD_INNER")) { const int v = atoi(e); if (v >= 1 && v <= 64) P.max_inner = (uint32_t)v; }
     // Slots: the heavy per-traversal structures (queue, sets: 3.6 MB at n_to_score = 100k) exist once per SLOT; a batch may
     // hold more traversals than slots (RADHIP_SHARD_SLOTS, row engine, product loop): a slot whose traversal is done takes

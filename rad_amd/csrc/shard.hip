@@ -46,7 +46,7 @@ int rh_trav_enqueue_shard_step(radhip_traversal *t);
 
 #define SH_EMPTY64 0ull
 
-struct ShardHeader {
+struct alignas(128) ShardHeader {   // one 128-B line: a slot's header is one request to load, one to store
     uint64_t n_scored, n_pops, n_nbr, heap_n;
     uint32_t prime_at, n_pend, pend_level;
     int32_t status;      // 0 running, 1 n_to_score reached, 2 queue empty, < 0 error
@@ -647,9 +647,9 @@ __global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
         H.n_scored = 0; H.n_pops = 0; H.n_nbr = 0; H.heap_n = 0; H.prime_at = 0; H.pend_level = 0; H.status = 0; H.n_vis = 0;
         H.spec_cnt[0] = H.spec_cnt[1] = 0;
         H.tid1 = t + 1u; H.epoch += 1u; H.no_more = 0;
+        if (gl == 0) *tidw = t;
     }
     const uint32_t tid = H.tid1 - 1u, epoch = H.epoch;
-    if (gl == 0) *tidw = tid;
     unsigned long long *heap = P.heap + (uint64_t)q * P.heap_stride;
     unsigned long long *vis = P.vis + ((uint64_t)q << P.vlog2);
     unsigned long long *sc = P.sc + ((uint64_t)q << P.slog2);

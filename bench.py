@@ -222,7 +222,7 @@ def run_traversal_leg(args, idx, batches, steps, warmup, barrier):
     note(f"{steps} timed steps done ({elapsed / max(steps, 1) * 1e3:.0f} ms each)")
     out = {"elapsed": elapsed, "pops": pops, "evals": evals, "nbrs": nbrs, "k_ms": k_ms, "launches": k_launches,
            "kernel": trav.kernel, "table": trav.table, "state_bytes": trav.state_bytes(), "last_stats": last,
-           "last_hashes": trav.result_hashes(0, min(trav.nq, 8192)),
+           "last_hashes": trav.result_hashes(0, trav.nq),
            "remids": float(last.n_remid.mean()), "repivots": float(last.n_repivot.mean()), "flushes": float(last.n_flush.mean())}
     trav.close()
     return out
@@ -790,11 +790,21 @@ def main():
     if world == 1:
         if not args.no_cpu_baseline:
             note("cpu_baseline: copying corpus and graph to the host")
-            cb, sample, ok = cpu_baseline(idx, batches[-1][:8192], leg["last_stats"], args, leg["last_hashes"])
+            # the parity sample alternates between the head and the tail of the batch: the first traversals of a launch are the
+            # ones its rows start with, the last ones are taken over by rows that have finished others (traverse4.inc `take`)
+            nqb, blk = batches[-1].shape[0], 32 * host_cores()
+            head = [np.arange(i, min(i + blk, nqb)) for i in range(0, min(4096, nqb), blk)]
+            tail = [np.arange(max(nqb - i - blk, 0), nqb - i) for i in range(0, min(4096, nqb), blk)]
+            sel = np.concatenate([x for pair in zip(head, tail) for x in pair])
+            sel = sel[np.sort(np.unique(sel, return_index=True)[1])]          # (small batches: head and tail overlap)
+            st_l = leg["last_stats"]
+            picked = type("S", (), {"n_scored": st_l.n_scored[sel], "n_pops": st_l.n_pops[sel], "n_nbr": st_l.n_nbr[sel]})
+            cb, sample, ok = cpu_baseline(idx, batches[-1][sel], picked, args, leg["last_hashes"][sel])
             note(f"cpu_baseline done, parity sample {sample}")
             out["cpu_baseline"] = cb
             out["parity_sample"] = sample
-            out["parity_sample_what"] = "oracle vs GPU per traversal: scored / expansions / neighbours counters AND a 64-bit order-sensitive hash of the whole scored list (slots, and, or)"
+            out["parity_sample_what"] = ("oracle vs GPU per traversal: scored / expansions / neighbours counters AND a 64-bit order-sensitive hash of the whole scored "
+                                         "list (slots, and, or); traversals taken alternately from the head and the tail of the last batch")
             if not ok:
                 raise SystemExit(f"bench.py: GPU and oracle disagree on the parity sample ({sample}): no value printed")
         if args.corpus_mode != 1 and not args.no_reference_corpus and args.graph == "built":

@@ -157,4 +157,19 @@ def test_bench_workload_itself_full_results_vs_oracle(gpu, oracle, monkeypatch):
         assert st.n_pops[i] == want.n_pops and st.n_nbr[i] == want.n_nbr
     assert (st.n_remid > 0).all()
     t.close()
+    # a batch larger than the device holds resident: the rows of the persistent wavefronts take its traversals from a
+    # counter — the LAST ones of the batch are taken over by rows that have finished others (hash of the whole scored list +
+    # the three counters against the oracle)
+    nqb = 2 * idx.traversal_capacity() + 4096
+    Qb = X[np.random.default_rng(78).integers(0, n, nqb)].copy()
+    tb = DeviceTraversal(idx, Qb, nts)
+    assert tb.kernel == "trav4_kernel" and tb.run() == 0
+    hb = tb.result_hashes(nqb - 6, 6)
+    sb = tb.stats()
+    for j in range(6):
+        i = nqb - 6 + j
+        want = oracle.rad_traverse(g, X, Qb[i], nts)
+        assert int(hb[j]) == oracle.result_hash(want.slots, want.and_cnt, want.or_cnt), i
+        assert sb.n_pops[i] == want.n_pops and sb.n_nbr[i] == want.n_nbr and sb.n_scored[i] == len(want.slots)
+    tb.close()
     idx.close()

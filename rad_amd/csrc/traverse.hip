@@ -1015,9 +1015,9 @@ static int trav_launch(radhip_traversal *t) {
     if (t->use4) {
         if (t->resident4 == 0) { uint32_t c = 0; RH_TRY(trav_capacity_of(idx, true, &c)); t->resident4 = c ? c : 4u; }
         // Rows that take their traversals from the counter: +2-4 % on rows of <= 16 slots (no row waits for the longest of
-        // its wavefront's four), but -25 % and worse on the WIDE form, whose rows then walk through their traversals out
-        // of phase (measured in one binary, profiles/r03/wide_rows_static_vs_counter.log): wide rows keep the static
-        // assignment.  RADHIP_TRAV_STATIC=1 / 0 forces either.
+        // its wavefront's four), a draw on the WIDE form (-2.5 % / -0.4 % at two / four resident rounds, one binary:
+        // profiles/r03/wide_rows_static_vs_counter.log), which keeps the static assignment.  RADHIP_TRAV_STATIC=1 / 0
+        // forces either.
         t->P.q_static = t->wide ? 1u : 0u;
         if (const char *e = getenv("RADHIP_TRAV_STATIC")) t->P.q_static = e[0] == '1' ? 1u : 0u;
         if (!t->P.q_static) grid4 = std::min<uint32_t>(grid4, t->resident4 / 4u);

@@ -624,6 +624,12 @@ __global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
     uint32_t *req = P.req + (uint64_t)q * P.Wt;
     uint32_t *tidw = P.req + (uint64_t)P.ns * P.Wt + q;         // which traversal's query the owners score this slot's candidates against
     uint32_t *live = P.req + (uint64_t)P.ns * P.Wt + P.ns;
+    // (the counter is asked, and its answer spread over the row, by every lane that is still here — outside the branch of the
+    // rows that want a traversal: traverse4.inc `take` found out why)
+    const bool wants = H.tid1 != 0u && H.status > 0 && H.epoch < 127u && !H.no_more;   // (a failed traversal keeps its slot: the error stays visible)
+    uint32_t t_next = 0xFFFFFFFFu;
+    if (wants && gl == 0) t_next = P.ns + atomicAdd(P.next_t, 1u);
+    t_next = (uint32_t)__shfl((int)t_next, 0, 16);
     if (H.tid1 == 0u || H.status != 0) {
         // nothing to work on: the slot's traversal is done (its results are in P.res), or this is the first step
         if (H.n_pend || H.n_spec) {
@@ -632,10 +638,7 @@ __global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
         }
         uint32_t t = 0xFFFFFFFFu;
         if (H.tid1 == 0u) t = q;                 // the first traversal of slot s is traversal s (what the host-staged exchange assumes)
-        else if (H.status >= 0 && H.epoch < 127u && !H.no_more) {   // (a failed traversal keeps its slot: the error stays visible)
-            if (gl == 0) t = P.ns + atomicAdd(P.next_t, 1u);
-            t = (uint32_t)__shfl((int)t, 0, 16);
-        }
+        else if (wants) t = t_next;
         if (t >= P.nq) {
             // (asked once: thousands of finished slots adding to one counter at every step cost more than the step)
             const bool first_no = !H.no_more;

@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Which row of which wavefront worked on which traversal (how profiles/r03/which_row_worked_on_which_traversal.log was made).
+Needs a library built with a one-line debug patch in save_row of rad_amd/csrc/traverse4.inc, after the header fields are
+written:      H->n_upper = blockIdx.x * 4u + g;
+(the statistics' n_upper field then carries the row's number).   python scripts/owner_debug.py <connectivity> <nq>"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np

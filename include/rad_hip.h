@@ -353,7 +353,8 @@ int radhip_shard_speculation(const radhip_shard_t *s, uint32_t *out_depth, uint6
 /* the same step in host-staged pieces, for an exchange the host program owns (tests; rehearsing N ranks
  * on one GPU): step -> get_requests | exchange | set_requests_all -> evaluate -> get_scores_out |
  * exchange (sum over ranks of block `rank`) | set_scores_in -> step ...   W = radhip_shard_width() slots
- * per traversal and step (RADHIP_NO_SLOT padded; the widest adjacency row, times 1 + the speculation depth); scores
+ * per traversal and step (RADHIP_NO_SLOT padded; the widest adjacency row, plus one more row width for all speculative
+ * candidates when speculation is on — RADHIP_SHARD_SPEC_ROWS=2 gives every speculative head its own); scores
  * are and | or << 16. */
 uint32_t radhip_shard_width(const radhip_shard_t *s);
 /* Slots of this shard: the queue and the sets of a traversal (3.6 MB at n_to_score = 100k) exist once per slot, and a slot

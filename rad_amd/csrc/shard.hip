@@ -1034,7 +1034,12 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     // (0.54 x the steps — and collectives — at 1.6 x the step: profiles/r03)
     uint32_t spec = (want_row && !wave) ? 2u : 0u;
     if (const char *e = getenv("RADHIP_SHARD_SPEC")) { const int v = atoi(e); if (v >= 0 && v <= 2 && !wave) spec = (uint32_t)v; }
-    const uint32_t W = Wrow * (1u + spec);
+    // one row width for what a traversal needs + ONE more for everything it asks speculatively (two heads have ~5 unscored
+    // neighbours each: they share 16 slots; a head whose candidates do not fit is simply not finished from the cache) —
+    // a third less to all-gather, scan and reduce-scatter per step than a row width per head
+    uint32_t spec_rows = spec ? 1u : 0u;
+    if (const char *e = getenv("RADHIP_SHARD_SPEC_ROWS")) { const int v = atoi(e); if (v >= 1 && v <= 2 && spec) spec_rows = (uint32_t)v < spec ? (uint32_t)v : spec; }
+    const uint32_t W = Wrow * (1u + spec_rows);
     s->W = W; s->Wrow = Wrow; s->spec = spec;
     const uint64_t n_top = idx->n_top;
     const uint64_t scored_cap = s->n_to_score + W + n_top;

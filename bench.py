@@ -715,14 +715,15 @@ def main():
     out["queue_per_traversal"] = {"repivots": leg["repivots"], "remids": leg["remids"], "flushes": leg["flushes"]}
     out["roofline"] = roofline_of(leg, B)
     out["build_id"] = _lib.build_id()
+    out["traverse_build_id"] = _lib.traverse_build_id()
     prof = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(prof):
         try:
             with open(prof) as f:
                 pj = json.load(f)
-            # measured offline (rocprofv3 --pmc passes): only valid for the kernels it was measured on — the library's
-            # build id (a hash of its sources) must match, or the figure is dropped, not printed
-            if (pj.get("build_id") == _lib.build_id() and pj.get("n") == n and pj.get("nq") == args.nq and pj.get("n_to_score") == args.n_to_score
+            # measured offline (rocprofv3 --pmc passes): only valid for the kernels it was measured on — the hash of the
+            # traversal kernels' sources must match, or the figure is dropped, not printed
+            if (pj.get("traverse_build_id") == _lib.traverse_build_id() and pj.get("n") == n and pj.get("nq") == args.nq and pj.get("n_to_score") == args.n_to_score
                     and pj.get("corpus_mode", 1) == args.corpus_mode and pj.get("table") == leg["table"]):
                 tr = pj.get("hbm_bytes_per_launch")
                 out["roofline"]["traffic"] = tr

@@ -55,6 +55,8 @@ const char *radhip_backend_name(void); /* "hip:gfx950" */
 int radhip_abi_version(void);
 /* 16 hex digits: a hash of every source file the library was built from (kernels included) */
 const char *radhip_build_id(void);
+/* the same for the traversal kernels alone (traverse.hip, traverse4.inc, common.h): the key of measured counters kept beside the code */
+const char *radhip_traverse_build_id(void);
 int radhip_device_count(int *out_count);
 
 /* ---- index: corpus + layered adjacency resident in HBM ----------------- */

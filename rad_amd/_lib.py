@@ -61,6 +61,7 @@ SIGNATURES = {
     "radhip_backend_name": (C.c_char_p, []),
     "radhip_abi_version": (C.c_int, []),
     "radhip_build_id": (C.c_char_p, []),
+    "radhip_traverse_build_id": (C.c_char_p, []),
     "radhip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "radhip_index_create": (C.c_int, [_U32, _U32, _U32, _U32, C.c_int, C.POINTER(_P)]),
     "radhip_index_destroy": (C.c_int, [_P]),
@@ -173,6 +174,10 @@ def check(rc: int) -> None:
 
 def build_id() -> str:
     return lib().radhip_build_id().decode("ascii", "replace")
+
+
+def traverse_build_id() -> str:
+    return lib().radhip_traverse_build_id().decode("ascii", "replace")
 
 
 def device_count() -> int:

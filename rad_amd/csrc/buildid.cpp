@@ -3,4 +3,8 @@
 #ifndef RADHIP_BUILD_ID
 #define RADHIP_BUILD_ID "unknown"
 #endif
+#ifndef RADHIP_TRAVERSE_ID
+#define RADHIP_TRAVERSE_ID "unknown"
+#endif
 extern "C" const char *radhip_build_id(void) { return RADHIP_BUILD_ID; }
+extern "C" const char *radhip_traverse_build_id(void) { return RADHIP_TRAVERSE_ID; }

@@ -30,7 +30,7 @@ pops = bj["value"] * bj["ms_per_step"] * 1e-3
 evals = bj["evals_per_s"] * bj["ms_per_step"] * 1e-3
 alg = bj["roofline"]["algorithmic_bytes_per_launch"]
 out = {
-    "build_id": _lib.build_id(), "kernel": kname, "table": bj["roofline"]["table"], "graph": "built", "corpus_mode": bj["config"]["corpus_mode"],
+    "build_id": _lib.build_id(), "traverse_build_id": _lib.traverse_build_id(), "kernel": kname, "table": bj["roofline"]["table"], "graph": "built", "corpus_mode": bj["config"]["corpus_mode"],
     "n": bj["config"]["rows"], "nq": bj["config"]["nq_per_gpu"], "n_to_score": bj["config"]["n_to_score"],
     "method": "rocprofv3 -f csv --kernel-trace --pmc <group> in separate passes over `python3 bench.py --no-cpu-baseline --no-reference-corpus "
               "--steps 1 --warmup 0` (scripts/profile_r03.sh), summed per kernel on the box; FETCH_SIZE x 2 per MI355X_MICROARCH.md "

@@ -1,6 +1,6 @@
 """debug: trav4 vs oracle on a mid-size closed-form graph with a long traversal (deep queue)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 os.environ["RADHIP_TRAV"] = "4"
 from oracle import rad_oracle as O

@@ -2,7 +2,7 @@
 """Experiment (GPU box): the statistics of scripts/locality_sim.py on the real bench graph
 (100M rows built on the GPU), traversals by the oracle on the host copy.
 
-    python scripts/locality_gpu.py [n_rows] [n_to_score] [n_queries]
+    python tests/tools/locality_gpu.py [n_rows] [n_to_score] [n_queries]
 """
 import ctypes as C
 import os
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import rad_oracle as O   # noqa: E402
 from rad_amd.device import DeviceIndex   # noqa: E402

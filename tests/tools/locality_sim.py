@@ -3,7 +3,7 @@
 expansion, and how many groups does a traversal touch in all, under graph-locality renumberings
 of the slots?  Uses the oracle builder/traversal on the bench's synthetic corpus at small n.
 
-    python scripts/locality_sim.py [n_rows] [n_to_score] [n_queries]
+    python tests/tools/locality_sim.py [n_rows] [n_to_score] [n_queries]
 """
 import ctypes as C
 import os
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import rad_oracle as O   # noqa: E402
 

@@ -832,10 +832,10 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
         t->use4 = true;
     } else {
         const int forced = trav_forced_kernel();
-        // rows wider than 16 slots (connectivity > 8): trav4_kernel's WIDE form walks a row in chunks of 16 (bucket table
-        // only: RADHIP_TABLE=hash / group keep such an index on trav_kernel)
+        // rows wider than 16 slots (connectivity > 8): trav4_kernel's WIDE form walks a row in chunks of 16 (bucket or grouped
+        // table: RADHIP_TABLE=hash keeps such an index on trav_kernel)
         const char *tb = getenv("RADHIP_TABLE");
-        const bool narrow = trav4_shape_ok(idx), wide = !narrow && idx->cap0 <= 64 && idx->M <= 64 && !(tb && (tb[0] == 'h' || tb[0] == 'g'));
+        const bool narrow = trav4_shape_ok(idx), wide = !narrow && idx->cap0 <= 64 && idx->M <= 64 && !(tb && tb[0] == 'h');
         // measured (profiles/r03): rows of 32 slots (the reference notebook's connectivity 16) are 14-40 % faster on the WIDE
         // form than on trav_kernel; rows of 64 (BASELINE config[4]: four chunks, four gather passes per pop) are not —
         // those stay on trav_kernel unless RADHIP_TRAV=4 asks
@@ -895,7 +895,7 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
         const char *e = getenv("RADHIP_TABLE");
         const bool force_group = e && e[0] == 'g';
         const uint32_t gt_log2 = std::max<uint32_t>(7, log2_ceil((scored_cap * 5 + 31) / 32));
-        const bool can = idx->layout_valid && idx->d_adjx0 && t->use4 && !t->wide && gt_log2 <= 17 && !sharded;
+        const bool can = idx->layout_valid && idx->d_adjx0 && t->use4 && gt_log2 <= 17 && !sharded;
         t->use_gt = can && force_group;
         P.gt_log2 = gt_log2;
         // Bucket table: trav4_kernel's default (RADHIP_TABLE=hash keeps the one-entry-per-probe table, for A/B runs).
@@ -904,7 +904,8 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
         t->use_bt = t->use4 && !t->use_gt && !sharded && !force_hash;
         P.bt_log2 = std::max<uint32_t>(6, log2_ceil((scored_cap * 5 + 7) / 8));
         P.bt_sbits = std::max<uint32_t>(8, log2_ceil(idx->g_n + 2));
-        if (P.bt_sbits > 30 || P.bt_log2 > 28) { t->use_bt = false; if (t->wide) { t->wide = false; t->use4 = false; } }
+        if (P.bt_sbits > 30 || P.bt_log2 > 28) t->use_bt = false;
+        if (t->wide && !t->use_bt && !t->use_gt) { t->wide = false; t->use4 = false; }   // (the WIDE form has no per-slot hash table variant)
         if (t->use_bt) t->epoch_max = (1u << (31u - P.bt_sbits)) - 1u;
         P.adjx0 = idx->d_adjx0; P.adjxU = idx->d_adjxU; P.topx = idx->d_topx; P.lid = idx->d_lid;
     }
@@ -1038,14 +1039,17 @@ static int trav_launch(radhip_traversal *t) {
 #define RH_K4H(LPR) trav4_kernel<LPR, false>
 #define RH_K4B(LPR) trav4_kernel<LPR, false, false, true>
 #define RH_K4W(LPR) trav4_kernel<LPR, false, false, true, true>
+#define RH_K4GW(LPR) trav4_kernel<LPR, true, false, false, true>
 #define RH_K1H(LPR) trav_kernel<LPR>
-    if (t->use4 && t->wide) { RH_TRAV_CASES(RH_K4W, grid4) }
+    if (t->use4 && t->wide && t->use_gt) { RH_TRAV_CASES(RH_K4GW, grid4) }
+    else if (t->use4 && t->wide) { RH_TRAV_CASES(RH_K4W, grid4) }
     else if (t->use4 && t->use_gt) { RH_TRAV_CASES(RH_K4G, grid4) }
     else if (t->use4 && t->use_bt) { RH_TRAV_CASES(RH_K4B, grid4) }
     else if (t->use4) { RH_TRAV_CASES(RH_K4H, grid4) }
     else { RH_TRAV_CASES(RH_K1H, t->nq) }
 #undef RH_K4B
 #undef RH_K4W
+#undef RH_K4GW
 #undef RH_K4G
 #undef RH_K4H
 #undef RH_K1H
@@ -1089,6 +1093,23 @@ static int trav_launch(radhip_traversal *t) {
 // only for an adversarial layout).  The batch has not returned anything yet: re-arm it with the per-slot
 // hash table, which has no such limit below its sized capacity, and run it again from the start.
 static int trav_fall_back_to_hash(radhip_traversal *t) {
+    if (t->wide) {   // the WIDE form has no per-slot hash variant: its fallback is the bucket table
+        const size_t bt_bytes = ((size_t)t->nq << (t->P.bt_log2 + 2)) * 4;
+        uint32_t *n_bt = nullptr;
+        hipError_t e = hipMalloc((void **)&n_bt, bt_bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP,
+                                     "hipMalloc(%zu) for the bucket-table fallback failed: %s", bt_bytes, hipGetErrorString(e)); }
+        if (t->P.gt) { (void)hipFree(t->P.gt); t->P.gt = nullptr; t->state_bytes -= t->gt_bytes; t->gt_bytes = 0; }
+        t->use_gt = false; t->use_bt = true;
+        t->P.bt = n_bt; t->bt_bytes = bt_bytes; t->state_bytes += bt_bytes;
+        t->epoch_max = (1u << (31u - t->P.bt_sbits)) - 1u;
+        t->fresh_tables = true;
+        const double ms = t->kernel_ms;
+        const uint64_t launches = t->launches;
+        RH_TRY(trav_upload_queries(t, t->h_queries.data()));
+        t->kernel_ms = ms; t->launches = launches;
+        return RADHIP_OK;
+    }
     // allocate first, release the grouped table only when the per-slot table exists
     const size_t ht_bytes = ((size_t)t->nq << t->ht_log2) * 8;
     unsigned long long *n_ht = nullptr;
@@ -1478,7 +1499,7 @@ extern "C" int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t 
     RH_TRY(rh_ensure_device(idx));
     const char *tb = getenv("RADHIP_TABLE");
     const int forced = trav_forced_kernel();
-    const bool wide_ok = idx->cap0 <= (forced == 4 ? 64u : 32u) && idx->M <= (forced == 4 ? 64u : 32u) && !(tb && (tb[0] == 'h' || tb[0] == 'g'));
+    const bool wide_ok = idx->cap0 <= (forced == 4 ? 64u : 32u) && idx->M <= (forced == 4 ? 64u : 32u) && !(tb && tb[0] == 'h');
     return trav_capacity_of(idx, (trav4_shape_ok(idx) || wide_ok) && forced != 1, out);
 }
 

@@ -31,8 +31,10 @@ for ef in (128, 400):
 print(f"n={n} {ndim}-bit connectivity={M} (level-0 width {2 * M}) expansion_add={ef_add}: Index build {tb:.1f} s ({n / tb / 1e6:.2f} M inserts/s), "
       f"recall@10 ef128 {rec[128]:.3f} ef400 {rec[400]:.3f}", flush=True)
 B = idx.info().row_stride
-for kern, mult in (("1", 1), ("1", 2), ("4", 1), ("4", 2), ("4", 4)):
+for kern, mult, table in (("1", 1, None), ("1", 2, None), ("4", 1, None), ("4", 2, None), ("4", 4, None), ("4", 2, "group"), ("4", 3, "group")):
     os.environ["RADHIP_TRAV"] = kern
+    if table: os.environ["RADHIP_TABLE"] = table
+    else: os.environ.pop("RADHIP_TABLE", None)
     cap = idx.traversal_capacity()
     nq = cap * mult
     try:

@@ -59,6 +59,29 @@ def test_grouped_table_matches_oracle_and_hash_table(gpu, oracle, monkeypatch, m
         assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt)
 
 
+@pytest.mark.parametrize("M,ndim,n,n_to_score", [(16, 1024, 12000, 2500), (32, 2048, 6000, 1500), (12, 512, 8000, 2000)])
+def test_grouped_table_on_wide_rows(gpu, oracle, monkeypatch, M, ndim, n, n_to_score):
+    """adjacency rows of 24 / 32 / 64 slots: trav4_kernel's WIDE form (a pop walks its row in chunks of 16) with the
+    grouped table against the oracle, and against the bucket table of the same form"""
+    monkeypatch.setenv("RADHIP_TRAV", "4")
+    idx, X, g = _index(oracle, n, ndim, M, 48, 2)
+    Q = X[np.random.default_rng(4).integers(0, n, 21)]
+    monkeypatch.delenv("RADHIP_TABLE", raising=False)
+    _check(oracle, idx, X, g, Q, n_to_score, "bucket")
+    monkeypatch.setenv("RADHIP_TABLE", "group")            # (computes the layout on first use)
+    _check(oracle, idx, X, g, Q, n_to_score, "grouped")
+    # an adversarial layout: every id on one chunk position -> the table fills up, the batch re-runs on the bucket table
+    lid = (np.arange(n, dtype=np.uint32) * 384).astype(np.uint32)
+    idx.set_layout(lid)
+    from rad_amd.device import DeviceTraversal
+    t = DeviceTraversal(idx, Q, n_to_score, log_pops=True)
+    assert t.run() == 0
+    for i in (0, 10, 20):
+        want = oracle.rad_traverse(g, X, Q[i], n_to_score)
+        s, a, o = t.results(i)
+        assert np.array_equal(s, want.slots) and np.array_equal(a, want.and_cnt) and np.array_equal(o, want.or_cnt)
+
+
 def test_layout_quality_on_hierarchical_corpus(gpu, oracle):
     idx, X, g = _index(oracle, 30000, 1024, 8, 64, 2)
     info = idx.optimize_layout()

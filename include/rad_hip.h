@@ -254,6 +254,17 @@ typedef struct {
 } radhip_trav_stats_t;
 
 #define RADHIP_TRAV_LOG_POPS 1u  /* keep the (node, level) expansion log      */
+/* Heavy state per RESIDENT ROW of the four-per-wavefront kernel instead of per traversal (round 4).  The visited / scored
+ * tables, the queue's key pool, run table and mid run of a traversal (2.5 MB at n_to_score = 100k) are what a resident
+ * row of the kernel works in; what a traversal owns by its number is its query, its header and its scored list (the
+ * output: rad/scored.py:63-85).  A row that is done with a traversal takes the next one of the batch and reuses its tables
+ * under a new epoch (the reference's per-run Redis keys, rad/traverser.py:93-102, restated as a tag in every entry).  A
+ * batch of 65536 traversals then needs 40 GB + 52 GB instead of 217 GB.  Such a batch runs to completion: max_pops and
+ * radhip_traversal_set_targets are refused.  Ignored where the four-per-wavefront kernel does not run or the batch fits
+ * one resident round (radhip_traversal_slots tells). */
+#define RADHIP_TRAV_SLOTS 4u
+/* The object gets a HIP stream of its own, so that radhip_traversal_start on one object overlaps the tail of another's launch */
+#define RADHIP_TRAV_OWN_STREAM 8u
 
 int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queries, uint32_t nq,
                             uint64_t n_to_score, uint32_t flags,
@@ -264,6 +275,16 @@ int radhip_traversal_reset(radhip_traversal_t *t, const uint8_t *queries);
 /* advance every unfinished traversal by at most max_pops expansions
  * (0 = run to completion); returns the number still running. */
 int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, uint32_t *out_running);
+/* The same as radhip_traversal_run(t, 0, ...) in two halves: start enqueues the launch of the re-armed batch and returns,
+ * finish waits for it and reports (capacity fallbacks included).  With two objects on two streams (RADHIP_TRAV_OWN_STREAM)
+ * the second batch's wavefronts start while the first batch's longest traversals are still running: the ~130 ms tail of a
+ * launch is paid once per run, not once per batch (request_work has no batch boundary either: rad/coordination_service.py:290). */
+int radhip_traversal_start(radhip_traversal_t *t);
+int radhip_traversal_finish(radhip_traversal_t *t, uint32_t *out_running);
+/* milliseconds on the device's clock from the start of `from`'s last launch to the end of `to`'s last launch */
+int radhip_traversal_elapsed_between(const radhip_traversal_t *from, const radhip_traversal_t *to, double *out_ms);
+/* resident rows whose state the batch shares (RADHIP_TRAV_SLOTS); 0 = state per traversal */
+uint32_t radhip_traversal_slots(const radhip_traversal_t *t);
 int radhip_traversal_stats(const radhip_traversal_t *t, radhip_trav_stats_t *out /* [nq] */);
 /* scored set of traversal q in insertion (traversal) order —
  * rad/scored.py:63-85 get_molecules; scores as integer (and, or) counts */

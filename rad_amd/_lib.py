@@ -16,6 +16,8 @@ LIB_PATH = os.environ.get("RADHIP_LIB") or os.path.join(_HERE, "_build", "librad
 NO_SLOT = 0xFFFFFFFF
 TRAV_LOG_POPS = 1
 SHARD_OWN_STREAM = 2
+TRAV_SLOTS = 4          # heavy traversal state per resident row of the kernel instead of per traversal
+TRAV_OWN_STREAM = 8     # the traversal object gets a HIP stream of its own (start / finish overlap)
 
 E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_STATE, E_CAPACITY, E_RANGE, E_COMM = range(-1, -9, -1)
 
@@ -102,6 +104,10 @@ SIGNATURES = {
     "radhip_traversal_destroy": (C.c_int, [_P]),
     "radhip_traversal_reset": (C.c_int, [_P, _P]),
     "radhip_traversal_run": (C.c_int, [_P, _U64, C.POINTER(_U32)]),
+    "radhip_traversal_start": (C.c_int, [_P]),
+    "radhip_traversal_finish": (C.c_int, [_P, C.POINTER(_U32)]),
+    "radhip_traversal_elapsed_between": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
+    "radhip_traversal_slots": (_U32, [_P]),
     "radhip_traversal_stats": (C.c_int, [_P, _P]),
     "radhip_traversal_results": (C.c_int, [_P, _U32, _P, _P, _P, _U64, C.POINTER(_U64)]),
     "radhip_traversal_pop_log": (C.c_int, [_P, _U32, _P, _P, _U64, C.POINTER(_U64)]),

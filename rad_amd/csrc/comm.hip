@@ -168,16 +168,27 @@ extern "C" int radhip_index_broadcast_graph(radhip_index_t *idx, radhip_comm_t *
     if (hipMemcpyAsync(dh, h, sizeof h, hipMemcpyHostToDevice, st) != hipSuccess) return fail(RADHIP_E_HIP);
     if ((rc = bcast_bytes(c, dh, sizeof h, root, st)) != RADHIP_OK) return fail(rc);
     if (hipMemcpyAsync(h, dh, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(RADHIP_E_HIP);
+    // Every rank checks the header against its own index BEFORE anything of the index changes, and all ranks agree on
+    // accept / reject (one word, all-reduced) before the bulk broadcasts: a receiver that rejected used to return while the
+    // root went on into ncclBroadcast and an unbounded wait.
+    unsigned long long verdict = 0;   // 0 = accept; else the reason
+    if (h[7] != 0x52414447ull) verdict = 1;
+    else if (h[5] != idx->cap0 || h[6] != idx->M) verdict = 2;
+    else if (!is_root && idx->sharded && idx->n_total != h[0]) verdict = 3;
+    unsigned long long agreed = verdict;
+    if (hipMemcpyAsync(dh, &verdict, 8, hipMemcpyHostToDevice, st) != hipSuccess) return fail(RADHIP_E_HIP);
+    if (ncclAllReduce(dh, dh, 1, ncclUint64, ncclMax, c->comm, st) != ncclSuccess) { radhip_set_error("graph broadcast: ncclAllReduce of the header verdict failed"); return fail(RADHIP_E_COMM); }
+    if (hipMemcpyAsync(&agreed, dh, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(RADHIP_E_HIP);
     (void)hipFree(dh);
-    if (h[7] != 0x52414447ull) RH_FAIL(RADHIP_E_COMM, "graph broadcast: bad header from rank %d", root);
-    if (h[5] != idx->cap0 || h[6] != idx->M)
+    if (verdict == 1) RH_FAIL(RADHIP_E_COMM, "graph broadcast: bad header from rank %d", root);
+    if (verdict == 2)
         RH_FAIL(RADHIP_E_INVALID, "graph broadcast: rank %d has rows of %llu / %llu slots, this index %u / %u", root, h[5], h[6], idx->cap0, idx->M);
+    if (verdict == 3)
+        RH_FAIL(RADHIP_E_INVALID, "graph broadcast: the graph has %llu nodes, this shard belongs to a corpus of %llu rows", h[0], (unsigned long long)idx->n_total);
+    if (agreed != 0) RH_FAIL(RADHIP_E_INVALID, "graph broadcast: another rank rejected the header of rank %d (reason %llu): nothing was broadcast", root, agreed);
     if (!is_root) {
         rh_layout_invalidate(idx);
         idx->g_n = h[0]; idx->max_level = (int32_t)(long long)h[1]; idx->entry = (uint32_t)h[2]; idx->n_upper_rows = h[3];
-        if (idx->sharded && idx->n_total != idx->g_n)
-            RH_FAIL(RADHIP_E_INVALID, "graph broadcast: the graph has %llu nodes, this shard belongs to a corpus of %llu rows",
-                    (unsigned long long)idx->g_n, (unsigned long long)idx->n_total);
         idx->has_graph = false; idx->d_graph_valid = false;
         RH_TRY(rh_alloc_graph_dev(idx));
         idx->n_top = (uint32_t)h[4];

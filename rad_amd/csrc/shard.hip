@@ -593,6 +593,7 @@ __device__ __forceinline__ unsigned long long shr_pop(unsigned long long *h, uin
 // Set entries of the row engine carry the slot's epoch (scored set: bits 57..63, visited set: bits 40..46): what an earlier
 // traversal of the slot left behind reads as empty.
 #define SHR_SC_EPOCH_SHIFT 57
+#define SHR_EPOCHS_PER_SLOT 127u   // traversals one slot can take between two clears of its sets (reset()): epochs 1..127
 #define SHR_VIS_EPOCH_SHIFT 40
 __device__ __forceinline__ bool shr_sc_free(unsigned long long e, uint32_t epoch) { return e == SH_EMPTY64 || (uint32_t)(e >> SHR_SC_EPOCH_SHIFT) != epoch; }
 __device__ __forceinline__ bool shr_vis_free(unsigned long long e, uint32_t epoch) { return e == SH_EMPTY64 || (uint32_t)(e >> SHR_VIS_EPOCH_SHIFT) != epoch; }
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(64) void shard_step_row_kernel(ShardParams P) {
     uint32_t *live = P.req + (uint64_t)P.ns * P.Wt + P.ns;
     // (the counter is asked, and its answer spread over the row, by every lane that is still here — outside the branch of the
     // rows that want a traversal: traverse4.inc `take` found out why)
-    const bool wants = H.tid1 != 0u && H.status > 0 && H.epoch < 127u && !H.no_more;   // (a failed traversal keeps its slot: the error stays visible)
+    const bool wants = H.tid1 != 0u && H.status > 0 && H.epoch < SHR_EPOCHS_PER_SLOT && !H.no_more;   // (a failed traversal keeps its slot: the error stays visible)
     uint32_t t_next = 0xFFFFFFFFu;
     if (wants && gl == 0) t_next = P.ns + atomicAdd(P.next_t, 1u);
     t_next = (uint32_t)__shfl((int)t_next, 0, 16);
@@ -1074,6 +1075,15 @@ extern "C" int radhip_shard_create(radhip_index_t *idx, int rank, int world, uin
     // the last one ends: with one slot per traversal half of the slot-steps of a batch are idle.
     uint32_t ns = nq;
     if (const char *e = getenv("RADHIP_SHARD_SLOTS")) { const long long v = atoll(e); if (v > 0 && (uint64_t)v < nq && s->row) ns = (uint32_t)v; }
+    // a slot's set entries carry a 7-bit epoch, one epoch per traversal it takes (1..127; the sets are cleared by reset()):
+    // with fewer than nq / 127 slots every slot would run out of epochs before the batch is done and the rest of the
+    // traversals would never run
+    if ((uint64_t)ns * SHR_EPOCHS_PER_SLOT < nq) {
+        lk.unlock();
+        radhip_shard_destroy(s);
+        RH_FAIL(RADHIP_E_INVALID, "RADHIP_SHARD_SLOTS=%u is too few for %u traversals per batch: a slot takes at most %u (need >= %u slots)",
+                ns, nq, SHR_EPOCHS_PER_SLOT, (nq + SHR_EPOCHS_PER_SLOT - 1u) / SHR_EPOCHS_PER_SLOT);
+    }
     s->ns = ns; P.ns = ns;
     int rc = RADHIP_OK;
     const size_t per_rank = (size_t)ns * W;
@@ -1302,6 +1312,7 @@ extern "C" int radhip_shard_set_scores_in(radhip_shard_t *s, const uint32_t *hos
 }
 
 static int shard_first_error(radhip_shard *s);
+static int shard_all_ran(radhip_shard *s);
 
 // wait for a stream with a deadline: a peer that died or left the loop must not hang this rank in a collective
 // for ever (RADHIP_SHARD_TIMEOUT_S, default 300 s per look; a look normally takes well under a second)
@@ -1410,10 +1421,17 @@ static int shard_run_groups(radhip_shard **S, radhip_comm **C, int ng, uint64_t 
         // stream is drained first so that nothing of this rank is left half-enqueued.
         char msg[400];
         snprintf(msg, sizeof msg, "%s", radhip_last_error());
-        for (int g = 0; g < ng; ++g) { (void)hipStreamSynchronize(S[g]->stream); if (C[g]->world > 1) (void)rh_comm_abort(C[g]); }
-        radhip_set_error("radhip_shard_run left the loop after %llu steps: %s%s", (unsigned long long)steps, msg,
-                         world > 1 ? " (communicator aborted: the peers' collectives fail instead of hanging)" : "");
-        return rc;
+        // Abort FIRST: when the failure is the deadline, or a peer that died, the stream still holds a collective
+        // that can never complete — an unbounded hipStreamSynchronize in front of ncclCommAbort would wait for it for ever.
+        // The abort makes the in-flight collective kernel exit; the stream is then drained with the same deadline as a look.
+        for (int g = 0; g < ng; ++g) if (C[g]->world > 1) (void)rh_comm_abort(C[g]);
+        bool drained = true;
+        for (int g = 0; g < ng; ++g) if (shard_sync(S[g]->stream) != RADHIP_OK) drained = false;
+        (void)hipGetLastError();
+        radhip_set_error("radhip_shard_run left the loop after %llu steps: %s%s%s", (unsigned long long)steps, msg,
+                         world > 1 ? " (communicator aborted: the peers' collectives fail instead of hanging)" : "",
+                         drained ? "" : "; the stream did not drain within the deadline either");
+        return drained ? rc : RADHIP_E_COMM;
     }
     lk.unlock();
     if (poisoned_by != 0xFFFFFFFFu) {
@@ -1424,6 +1442,8 @@ static int shard_run_groups(radhip_shard **S, radhip_comm **C, int ng, uint64_t 
                 poisoned_by, (unsigned long long)steps);
     }
     for (int g = 0; g < ng; ++g) RH_TRY(shard_first_error(S[g]));
+    if (!(max_steps && steps >= max_steps))   // the loop ended because nothing was live: then every traversal of the batch has run
+        for (int g = 0; g < ng; ++g) RH_TRY(shard_all_ran(S[g]));
     return RADHIP_OK;
 }
 
@@ -1455,6 +1475,17 @@ static int shard_first_error(radhip_shard *s) {
     RH_HIP(hipMemcpy(res.data(), s->P.res, (size_t)s->nq * sizeof(ShardResult), hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < s->nq; ++i)
         if (res[i].status < 0) RH_FAIL(res[i].status, "sharded traversal %u overflowed a fixed-capacity device structure (status %d)", i, res[i].status);
+    return RADHIP_OK;
+}
+
+// the loop ended with no live traversal anywhere: a traversal whose result is still "not started" (status 0, nothing
+// scored) was never taken by a slot — results must not be silently missing
+static int shard_all_ran(radhip_shard *s) {
+    if (s->wave) return RADHIP_OK;
+    std::vector<ShardResult> res(s->nq);
+    RH_HIP(hipMemcpy(res.data(), s->P.res, (size_t)s->nq * sizeof(ShardResult), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < s->nq; ++i)
+        if (res[i].status == 0) RH_FAIL(RADHIP_E_STATE, "sharded traversal %u of %u never ran (%u slots ran out of epochs?): results are incomplete", i, s->nq, s->ns);
     return RADHIP_OK;
 }
 

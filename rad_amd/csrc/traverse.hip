@@ -25,222 +25,8 @@
 //           sorted runs; they are not looked at again until the near set runs dry, when the
 //           pivot is raised and the run prefixes / staging keys below it move to registers.
 //   Invariant: every far key >= pivot, so a near key below the pivot is the global minimum.
-#include "common.h"
+#include "traverse_dev.h"
 
-#include <algorithm>
-#include <new>
-
-#ifndef RH_S_CAP
-#define RH_S_CAP 512
-#endif
-#ifndef RH_MAX_RUNS
-#define RH_MAX_RUNS 8192
-#endif
-#define S_CAP ((uint32_t)RH_S_CAP)
-#define MAX_RUNS ((uint32_t)RH_MAX_RUNS)
-#define RK 4
-#define HT_EMPTY64 0xFFFFFFFFFFFFFFFFull
-#define VAL_V0 (1u << 24)
-// Lazy clearing: bits 31..25 of an entry's value word carry the epoch of the batch that wrote it
-// (0x7F, what the 0xFF memset leaves, is never a live epoch); entries of older epochs read as empty,
-// so re-arming the state for a new batch of queries does not touch the tables (49 GB at bench size).
-// Home bucket of a slot: multiplicative hash.  (A variant that keeps 16 consecutive slots in one
-// 128-B line of the table was measured slower, with and without a cluster-contiguous
-// renumbering of the corpus: profiles/r01/README.md.)
-#define RH_HT_HASH(s) (((s) * 2654435769u) >> ht_shift)
-#define VAL_EPOCH_SHIFT 25
-#define EPOCH_LIMIT 127u
-#define DQ_INIT (1u << 14)
-#define DQ_MAX (1u << 23)
-
-// One wave per workgroup: LDS traffic of a single wave is executed in issue order, so
-// cross-lane hand-offs through LDS need only a compiler barrier — not the
-// s_waitcnt vmcnt(0) that __syncthreads() adds (it would stall on every outstanding store).
-#define WSYNC()                                                  \
-    do {                                                         \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
-        __builtin_amdgcn_wave_barrier();                         \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
-    } while (0)
-
-struct TravHeader {
-    uint64_t n_scored, n_pops, n_nbr, pq_used, n_upper;
-    uint64_t target;        // stop once n_scored >= target (checked before every pop)
-    uint64_t frontier_key;  // best queue key when the kernel last returned (RH_KEY_INF = empty)
-    uint64_t pivot;
-    uint64_t n_repivot, n_flush;
-    uint32_t stg_cnt, n_runs, qpop, primed;
-    uint32_t dq, mid_pos;
-    int32_t status;
-    uint32_t dm;
-    // trav4_kernel's three-level queue: keys below mid_limit are in registers / staging / the mid run
-    // [mid_pos, mid_end) of the key pool; the far runs hold keys >= mid_limit only
-    uint64_t mid_limit, far_min;
-    uint32_t mid_end, n_remid;
-    // row-sharded form of trav4_kernel: candidates out (count | level << 8 | lane rotation << 16), entry points primed
-    uint32_t sh_pend, sh_prime_at;
-};
-
-struct TravParams {
-    const uint4 *fp;
-    const uint32_t *adj0, *upper_row, *adjU, *top;
-    uint32_t n_top, cap0, capU, nq;
-    int32_t start_level;
-    uint32_t epoch;          // current batch (see VAL_EPOCH_SHIFT)
-    uint32_t spread_shift;   // new keys of an expansion go to lanes (i << spread_shift) + rot
-    uint32_t spec_passes;    // 1 or 2: speculative row gathers cover every neighbour; 0: disabled
-    uint64_t n_to_score, max_pops;
-    TravHeader *hdr;
-    const uint4 *queries;
-    unsigned long long *ht;  // {slot | val<<32}
-    uint32_t ht_log2;
-    // bucket table (trav4_kernel<.., BT = true>, traverse4.inc): per traversal 2^bt_log2 buckets of four u32 entries
-    // (slot + 1) | epoch << bt_sbits | v0 << 31; epochs 1 .. 2^(31 - bt_sbits) - 1, 0 = cleared
-    uint32_t *bt;
-    uint32_t bt_log2, bt_sbits;
-    unsigned long long *ut;
-    uint32_t ut_log2;
-    // grouped visited/scored table (GT kernels; needs the index's graph-locality layout, layout.hip):
-    // per traversal 2^gt_log2 lines of 8 chunks {tag, 48 seen bits, 48 pend bits}, see traverse4.inc
-    const uint2 *adjx0, *adjxU, *topx;   // {slot, layout id} pair rows
-    const uint32_t *lid;
-    unsigned long long *gt;              // [nq << (gt_log2 + 4)] (two u64 per chunk)
-    uint32_t gt_log2;
-    uint2 *scored;
-    uint64_t scored_cap;
-    unsigned long long *pq;
-    uint64_t pq_cap;
-    unsigned long long *stg_save;  // [nq * S_CAP]
-    unsigned long long *r_save;    // [nq * RK * 64] near keys
-    uint32_t max_runs;             // run-table entries per traversal: 8192, more for n_to_score beyond ~400k
-    uint2 *runs;                   // [nq * max_runs] {pos, end}
-    unsigned long long *rhead;     // [nq * MAX_RUNS] head key of every run (INF = exhausted)
-    unsigned long long *midpool;   // trav4_kernel: [nq * 256] the sorted mid run of every traversal
-    uint32_t *q_next;              // trav4_kernel: the next traversal of the batch a free row takes (zeroed before every launch)
-    uint32_t q_static;             // 1: a row keeps the traversal its block index names and takes no other (grid = nq / 4)
-    uint32_t *poplog_nodes;
-    uint8_t *poplog_levels;
-    uint64_t poplog_cap;
-    unsigned long long *prof;   // RH_PROFILE builds only: per-section cycle sums
-    // row-sharded form (trav4_kernel<LPR, false, true>, shard.hip): candidate slots out, packed counts in
-    uint32_t *sh_req;              // [nq * sh_W + 16]: this step's candidates (NO_SLOT padded), then the live count
-    const uint32_t *sh_in;         // [nq * sh_W]: and | or << 16 of the last step's candidates
-    uint32_t *sh_pend_h;           // [nq * 16]: the table bucket every candidate out has claimed
-    uint32_t sh_W;
-};
-
-__device__ __forceinline__ unsigned long long ld64(const unsigned long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool ht_is_empty(unsigned long long e, uint32_t epoch) { return (uint32_t)(e >> 57) != epoch; }
-// test-and-set of (slot<<4|level) in the upper-level visited set; entries of older epochs are free
-__device__ __forceinline__ bool ut_test_and_set(unsigned long long *ut, uint32_t mask, uint32_t shift,
-                                                unsigned long long body, uint32_t epoch) {
-    const unsigned long long kk = (((unsigned long long)epoch << 40) | body) + 1ull;
-    uint32_t h = (uint32_t)(((body + 1ull) * 0x9E3779B97F4A7C15ull) >> shift);
-    for (;;) {
-        const unsigned long long old = atomicCAS(&ut[h], 0ull, kk);
-        if (old == 0ull) return true;
-        if (old == kk) return false;
-        if (((old - 1ull) >> 40) != (unsigned long long)epoch) {   // stale: take it over
-            if (atomicCAS(&ut[h], old, kk) == old) return true;
-            continue;                                              // another lane got there first: look again
-        }
-        h = (h + 1u) & mask;
-    }
-}
-__device__ __forceinline__ void st_relaxed(uint32_t *p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Decimal tables of the queue key (the member string "{node}:{level}" is kept as a zero-padded decimal).  A select
-// chain or comparison tree over a per-lane value compiles to a tree of exec-mask branches, ~50 scalar instructions
-// per use; a table read from LDS is one.
-struct KeyTabs {
-    uint32_t pow10[16];      // 10^e, e = 0..9
-    uint2 div10[16];         // {m, s}: n / 10^e == umulhi(n, m) >> s for n < 2^30, e = 1..9
-};
-__device__ __forceinline__ void keytabs_init(KeyTabs &T, uint32_t lane) {   // lanes 0..15 of a wavefront; sync before use
-    if (lane < 16u) {
-        uint32_t p = 1u;
-        for (uint32_t i = 0; i < lane && i < 9u; ++i) p *= 10u;
-        T.pow10[lane] = p;
-        uint32_t l = 0;
-        while ((1u << l) < p) l++;
-        // m = floor(2^(30+l) / p) + 1 < 2^32; exact for n < 2^30 because 2^l > p (p is not a power of two for e >= 1)
-        T.div10[lane] = lane == 0u ? make_uint2(0u, 0u) : make_uint2((uint32_t)(((1ull << (30u + l)) / p) + 1ull), l - 2u);
-    }
-}
-// slot of a key: (p + 1) / 10^dl - 1
-__device__ __forceinline__ uint32_t key_slot_tab(const KeyTabs &T, unsigned long long key) {
-    const uint32_t n = ((uint32_t)(key >> 8) & 0x3FFFFFFFu) + 1u, e = (uint32_t)(key >> 4) & 0xFu;
-    const uint2 ms = T.div10[e];
-    return (e ? (__umulhi(n, ms.x) >> ms.y) : n) - 1u;
-}
-// rh_make_key (common.h): digits = floor(log10) estimate from the bit length, one compare to fix it
-__device__ __forceinline__ unsigned long long make_key_tab(const KeyTabs &T, uint32_t q24, uint32_t slot, uint32_t level) {
-    const uint32_t bits = 32u - (uint32_t)__clz((int)(slot | 1u));
-    const uint32_t t = (bits * 1233u) >> 12;                    // digits - 1 or digits
-    const uint32_t d = t + ((slot | 1u) >= T.pow10[t] ? 1u : 0u);
-    const uint32_t dl = 9u - d;
-    const uint32_t p = (slot + 1u) * T.pow10[dl] - 1u;
-    return ((unsigned long long)q24 << 38) | ((unsigned long long)p << 8) | ((unsigned long long)dl << 4) | (unsigned long long)rh_level_rank(level);
-}
-
-struct TravLds {
-    KeyTabs kt;
-    unsigned long long stg[S_CAP];
-    uint32_t new_slot[64];
-    uint32_t new_h[64];
-    uint32_t new_and[64];
-    uint32_t new_or[64];
-    uint32_t claim[128];
-    uint32_t claimtab[128];   // buckets claimed by the expansion in flight (0 = free)
-};
-
-// ascending in-place bitonic sort of s[0..P), P a power of two, by one wave
-__device__ void lds_bitonic_sort(unsigned long long *s, uint32_t P, uint32_t lane) {
-    for (uint32_t k = 2; k <= P; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = lane; t < (P >> 1); t += 64) {
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t ixj = i | j;
-                const bool up = (i & k) == 0;
-                const unsigned long long a = s[i], b = s[ixj];
-                if ((a > b) == up) { s[i] = b; s[ixj] = a; }
-            }
-            WSYNC();
-        }
-    }
-}
-
-// insert x into the lane's sorted keys k0<=k1<=k2<=k3 (RH_KEY_INF = free); returns the key that
-// fell off the end (the largest of the five), RH_KEY_INF if there was room or x was INF
-__device__ __forceinline__ unsigned long long r_insert(unsigned long long x, unsigned long long &k0,
-                                                       unsigned long long &k1, unsigned long long &k2,
-                                                       unsigned long long &k3) {
-    unsigned long long t = x, a;
-    if (t < k0) { a = k0; k0 = t; t = a; }
-    if (t < k1) { a = k1; k1 = t; t = a; }
-    if (t < k2) { a = k2; k2 = t; t = a; }
-    if (t < k3) { a = k3; k3 = t; t = a; }
-    return t;
-}
-
-__device__ __forceinline__ uint32_t key_slot(unsigned long long key) {
-    const uint32_t p1 = ((uint32_t)(key >> 8) & 0x3FFFFFFFu) + 1u;
-    switch ((uint32_t)(key >> 4) & 0xFu) {   // wave-uniform at the only call site
-        case 0: return p1 - 1u;
-        case 1: return p1 / 10u - 1u;
-        case 2: return p1 / 100u - 1u;
-        case 3: return p1 / 1000u - 1u;
-        case 4: return p1 / 10000u - 1u;
-        case 5: return p1 / 100000u - 1u;
-        case 6: return p1 / 1000000u - 1u;
-        case 7: return p1 / 10000000u - 1u;
-        default: return p1 / 100000000u - 1u;
-    }
-}
 
 template <int LPR>
 __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
@@ -698,7 +484,6 @@ __global__ __launch_bounds__(64, 6) void trav_kernel(TravParams P) {
     }
 }
 
-#include "traverse4.inc"
 
 // ================================================================== host side
 struct radhip_traversal {
@@ -727,6 +512,14 @@ struct radhip_traversal {
     double kernel_ms = 0.0;
     uint64_t launches = 0;
     uint64_t state_bytes = 0;
+    // round 4: heavy state per resident row instead of per traversal (RADHIP_TRAV_SLOTS), and launches that do not wait
+    // (radhip_traversal_start / _finish on a stream of the object's own, RADHIP_TRAV_OWN_STREAM)
+    uint32_t sn = 0;               // state sets allocated: nq, or the slots
+    size_t slot_epoch_bytes = 0;
+    hipStream_t stream = nullptr;  // the index's stream, or the object's own
+    bool own_stream = false;
+    bool in_flight = false;        // started, not finished yet
+    bool first_pending = false;    // the launch in flight is the first of its batch (capacity fallbacks may re-run it)
 };
 
 static uint32_t log2_ceil(uint64_t x) {
@@ -757,19 +550,34 @@ static int trav_upload_queries(radhip_traversal *t, const uint8_t *queries) {
         hdr[i].far_min = RH_KEY_INF;
         hdr[i].dm = 1u << 12;
     }
-    RH_HIP(hipMemcpyAsync(t->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, idx->stream));
-    RH_HIP(hipMemcpyAsync(t->P.hdr, hdr.data(), t->hdr_bytes, hipMemcpyHostToDevice, idx->stream));
+    if (t->in_flight) RH_FAIL(RADHIP_E_STATE, "the traversal object has a launch in flight: radhip_traversal_finish first");
+    hipStream_t st = t->stream;
+    RH_HIP(hipMemcpyAsync(t->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, st));
+    RH_HIP(hipMemcpyAsync(t->P.hdr, hdr.data(), t->hdr_bytes, hipMemcpyHostToDevice, st));
+    if (t->P.slots) {
+        // per-row epochs live on the device (a row bumps its own when it takes a traversal and clears its own tables when
+        // they run out): re-arming a batch touches no table at all
+        if (t->fresh_tables) {
+            t->fresh_tables = false;
+            if (t->P.ht) RH_HIP(hipMemsetAsync(t->P.ht, 0xFF, t->ht_bytes, st));
+            if (t->P.gt) RH_HIP(hipMemsetAsync(t->P.gt, 0xFF, t->gt_bytes, st));
+            if (t->P.bt) RH_HIP(hipMemsetAsync(t->P.bt, 0x00, t->bt_bytes, st));
+            RH_HIP(hipMemsetAsync(t->P.ut, 0x00, t->ut_bytes, st));
+            // "nothing yet": epoch_first - 1 (the bucket table's live epochs start at 1, the others' at 0 = 0xFFFFFFFF + 1)
+            RH_HIP(hipMemsetAsync(t->P.slot_epoch, t->use_bt ? 0x00 : 0xFF, t->slot_epoch_bytes, st));
+        }
+    } else
     if (t->fresh_tables || ++t->P.epoch > t->epoch_max) {   // first use, or epoch space exhausted: really clear
         // (the bucket table's cleared state is 0 = epoch 0, so its live epochs start at 1; the other tables clear to
         // all-ones = epoch 0x7F and count from 0.  At 1B rows a bucket entry has one epoch bit: cleared every batch.)
         t->P.epoch = t->use_bt ? 1u : 0u;
         t->fresh_tables = false;
-        if (t->P.ht) RH_HIP(hipMemsetAsync(t->P.ht, 0xFF, t->ht_bytes, idx->stream));
-        if (t->P.gt) RH_HIP(hipMemsetAsync(t->P.gt, 0xFF, t->gt_bytes, idx->stream));
-        if (t->P.bt) RH_HIP(hipMemsetAsync(t->P.bt, 0x00, t->bt_bytes, idx->stream));
-        RH_HIP(hipMemsetAsync(t->P.ut, 0x00, t->ut_bytes, idx->stream));
+        if (t->P.ht) RH_HIP(hipMemsetAsync(t->P.ht, 0xFF, t->ht_bytes, st));
+        if (t->P.gt) RH_HIP(hipMemsetAsync(t->P.gt, 0xFF, t->gt_bytes, st));
+        if (t->P.bt) RH_HIP(hipMemsetAsync(t->P.bt, 0x00, t->bt_bytes, st));
+        RH_HIP(hipMemsetAsync(t->P.ut, 0x00, t->ut_bytes, st));
     }
-    RH_HIP(hipStreamSynchronize(idx->stream));
+    RH_HIP(hipStreamSynchronize(st));
     t->kernel_ms = 0.0;
     t->launches = 0;
     return RADHIP_OK;
@@ -793,6 +601,8 @@ extern "C" int radhip_traversal_destroy(radhip_traversal_t *t) {
     if (t->P.q_next) (void)hipFree(t->P.q_next);
     if (t->P.r_save) (void)hipFree(t->P.r_save);
     if (t->P.sh_pend_h) (void)hipFree(t->P.sh_pend_h);
+    if (t->P.slot_epoch) (void)hipFree(t->P.slot_epoch);
+    if (t->own_stream && t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
     if (t->P.poplog_nodes) (void)hipFree(t->P.poplog_nodes);
     if (t->P.poplog_levels) (void)hipFree(t->P.poplog_levels);
     if (t->ev0) (void)hipEventDestroy(t->ev0);
@@ -827,6 +637,11 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
     radhip_traversal *t = new (std::nothrow) radhip_traversal();
     if (!t) RH_FAIL(RADHIP_E_NOMEM, "out of host memory");
     t->idx = idx; t->nq = nq; t->n_to_score = n_to_score; t->flags = flags; t->sharded = sharded;
+    t->stream = idx->stream;
+    if ((flags & RADHIP_TRAV_OWN_STREAM) && !sharded) {
+        if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) { delete t; (void)hipGetLastError(); RH_FAIL(RADHIP_E_HIP, "hipStreamCreate failed"); }
+        t->own_stream = true;
+    }
     if (sharded) {
         if (!trav4_shape_ok(idx)) { delete t; RH_FAIL(RADHIP_E_INVALID, "the wave engine needs adjacency rows of at most 16 slots"); }
         t->use4 = true;
@@ -909,20 +724,39 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
         if (t->use_bt) t->epoch_max = (1u << (31u - P.bt_sbits)) - 1u;
         P.adjx0 = idx->d_adjx0; P.adjxU = idx->d_adjxU; P.topx = idx->d_topx; P.lid = idx->d_lid;
     }
+    // RADHIP_TRAV_SLOTS: tables, key pool, run table and mid pool once per RESIDENT ROW of trav4_kernel instead of once per
+    // traversal (bucket or grouped table; the flag is ignored where that kernel is not the one that runs).  The rows are
+    // the device's: a batch of any size needs the same 40 GB (n_to_score = 100k) plus 0.8 MB of scored list per traversal.
+    t->sn = nq;
+    if ((flags & RADHIP_TRAV_SLOTS) && t->use4 && (t->use_bt || t->use_gt) && !sharded) {
+        uint32_t c = 0;
+        int rc4 = trav_capacity_of(idx, true, &c);
+        if (rc4 != RADHIP_OK) { radhip_traversal_destroy(t); return rc4; }
+        t->resident4 = c ? c : 4u;
+        if (nq > t->resident4) { t->sn = t->resident4; P.slots = t->sn; }   // (a batch that fits one resident round gains nothing)
+        // (test hooks: a handful of rows for a small batch, so that every row works through many traversals; few epochs,
+        // so that rows run out of them and clear their own tables)
+        if (const char *e = getenv("RADHIP_TEST_SLOTS")) { const int v = atoi(e); if (v >= 4 && (uint32_t)v < nq) { t->sn = ((uint32_t)v + 3u) & ~3u; P.slots = t->sn; } }
+        if (const char *e = getenv("RADHIP_TEST_EPOCH_MAX")) { const int v = atoi(e); if (v >= 1 && (uint32_t)v < t->epoch_max) t->epoch_max = (uint32_t)v; }
+    }
+    const size_t sn = t->sn;
+    P.epoch_first = t->use_bt ? 1u : 0u;
+    P.epoch_max = t->epoch_max;
     t->hdr_bytes = (size_t)nq * sizeof(TravHeader);
-    t->gt_bytes = t->use_gt ? ((size_t)nq << (P.gt_log2 + 4)) * 8 : 0;
-    t->bt_bytes = t->use_bt ? ((size_t)nq << (P.bt_log2 + 2)) * 4 : 0;
-    t->ht_bytes = (t->use_gt || t->use_bt) ? 0 : ((size_t)nq << ht_log2) * 8;
-    t->ut_bytes = ((size_t)nq << ut_log2) * 8;
+    t->gt_bytes = t->use_gt ? (sn << (P.gt_log2 + 4)) * 8 : 0;
+    t->bt_bytes = t->use_bt ? (sn << (P.bt_log2 + 2)) * 4 : 0;
+    t->ht_bytes = (t->use_gt || t->use_bt) ? 0 : (sn << ht_log2) * 8;
+    t->ut_bytes = (sn << ut_log2) * 8;
     t->scored_bytes = (size_t)nq * scored_cap * sizeof(uint2);
-    t->pq_bytes = (size_t)nq * pq_cap * 8;
-    t->stg_bytes = (size_t)nq * S_CAP * 8;
+    t->pq_bytes = sn * pq_cap * 8;
+    t->stg_bytes = P.slots ? 0 : (size_t)nq * S_CAP * 8;
     // a far run is written by a staging flush (64-256 keys) and stays in the table while it holds a key:
     // scored_cap / 48 entries cover that with a margin, 8192 at least (exhausted runs are collected on the device)
     P.max_runs = std::max<uint32_t>(MAX_RUNS, 1u << log2_ceil(scored_cap / 48 + 1));
-    t->runs_bytes = (size_t)nq * P.max_runs * sizeof(uint2);
-    t->rhead_bytes = (size_t)nq * P.max_runs * 8;
-    t->rsave_bytes = (size_t)nq * RK * 64 * 8;
+    t->runs_bytes = sn * P.max_runs * sizeof(uint2);
+    t->rhead_bytes = sn * P.max_runs * 8;
+    t->rsave_bytes = P.slots ? 0 : (size_t)nq * RK * 64 * 8;
+    t->slot_epoch_bytes = P.slots ? sn * 4 : 0;
     int rc = RADHIP_OK;
 #define RH_A(ptr, bytes)                                                                   \
     do {                                                                                   \
@@ -944,9 +778,10 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
     if (rc == 0) RH_A(P.stg_save, t->stg_bytes);
     if (rc == 0) RH_A(P.runs, t->runs_bytes);
     if (rc == 0) RH_A(P.rhead, t->rhead_bytes);
-    if (rc == 0) RH_A(P.midpool, (size_t)nq * 256 * 8);
+    if (rc == 0) RH_A(P.midpool, sn * 256 * 8);
     if (rc == 0) RH_A(P.q_next, 64);
     if (rc == 0) RH_A(P.r_save, t->rsave_bytes);
+    if (rc == 0 && P.slots) RH_A(P.slot_epoch, t->slot_epoch_bytes);
     if (rc == 0 && sharded) RH_A(P.sh_pend_h, (size_t)nq * 16 * 4);
     if (rc == 0 && (flags & RADHIP_TRAV_LOG_POPS)) {
         P.poplog_cap = pq_cap;
@@ -983,8 +818,7 @@ int rh_trav_enqueue_shard_step(radhip_traversal *t) {
     if (!t->sharded || !t->P.sh_req) RH_FAIL(RADHIP_E_STATE, "not a sharded traversal");
     const uint32_t grid = (t->nq + 3u) / 4u;
     // (the fingerprint width only matters to the gather, which this form does not have: one instantiation)
-    hipLaunchKernelGGL((trav4_kernel<8, false, true>), dim3(grid), dim3(64), 0, idx->stream, t->P);
-    RH_HIP(hipGetLastError());
+    RH_TRY(rh_trav4_launch_sharded(grid, idx->stream, t->P));
     t->launches++;
     return RADHIP_OK;
 }
@@ -999,9 +833,10 @@ extern "C" int radhip_traversal_reset(radhip_traversal_t *t, const uint8_t *quer
     return trav_upload_queries(t, queries);
 }
 
-// one launch of the kernel the object is bound to, to completion of the stream; kernel time accumulated
-static int trav_launch(radhip_traversal *t) {
+// one launch of the kernel the object is bound to, enqueued on the object's stream between its two events (no wait)
+static int trav_enqueue(radhip_traversal *t) {
     radhip_index *idx = t->idx;
+    hipStream_t st = t->stream;
 #ifdef RH_PROFILE
     static unsigned long long *d_prof = nullptr;
     if (!d_prof) { (void)hipMalloc((void **)&d_prof, 256); }
@@ -1021,42 +856,32 @@ static int trav_launch(radhip_traversal *t) {
         // forces either.
         t->P.q_static = t->wide ? 1u : 0u;
         if (const char *e = getenv("RADHIP_TRAV_STATIC")) t->P.q_static = e[0] == '1' ? 1u : 0u;
+        if (t->P.slots) t->P.q_static = 0u;   // (a row's state serves whatever traversals the row takes)
         if (!t->P.q_static) grid4 = std::min<uint32_t>(grid4, t->resident4 / 4u);
         // (test hook: a grid of a few wavefronts, so that small batches exercise rows that take many traversals in a row)
         if (const char *e = getenv("RADHIP_TEST_GRID")) { const int v = atoi(e); if (v > 0 && !t->P.q_static) grid4 = std::min<uint32_t>(grid4, (uint32_t)v); }
-        RH_HIP(hipMemsetAsync(t->P.q_next, 0, 4, idx->stream));
+        if (t->P.slots && grid4 * 4u > t->P.slots) grid4 = t->P.slots / 4u;
+        RH_HIP(hipMemsetAsync(t->P.q_next, 0, 4, st));
     }
-    RH_HIP(hipEventRecord(t->ev0, idx->stream));
-#define RH_TRAV_CASES(KERNEL, GRID)                                                                              \
-    switch (idx->lpr) {                                                                                          \
-        case 1: hipLaunchKernelGGL((KERNEL(1)), dim3(GRID), dim3(64), 0, idx->stream, t->P); break;              \
-        case 2: hipLaunchKernelGGL((KERNEL(2)), dim3(GRID), dim3(64), 0, idx->stream, t->P); break;              \
-        case 4: hipLaunchKernelGGL((KERNEL(4)), dim3(GRID), dim3(64), 0, idx->stream, t->P); break;              \
-        case 8: hipLaunchKernelGGL((KERNEL(8)), dim3(GRID), dim3(64), 0, idx->stream, t->P); break;              \
-        default: hipLaunchKernelGGL((KERNEL(16)), dim3(GRID), dim3(64), 0, idx->stream, t->P); break;            \
+    RH_HIP(hipEventRecord(t->ev0, st));
+    if (t->use4) {
+        RH_TRY(rh_trav4_launch(t->use_gt ? RH_T4_GROUPED : t->use_bt ? RH_T4_BUCKET : RH_T4_HASH, t->wide, t->P.slots != 0u, (int)idx->lpr, grid4, st, t->P));
+    } else {
+        switch (idx->lpr) {
+            case 1: hipLaunchKernelGGL((trav_kernel<1>), dim3(t->nq), dim3(64), 0, st, t->P); break;
+            case 2: hipLaunchKernelGGL((trav_kernel<2>), dim3(t->nq), dim3(64), 0, st, t->P); break;
+            case 4: hipLaunchKernelGGL((trav_kernel<4>), dim3(t->nq), dim3(64), 0, st, t->P); break;
+            case 8: hipLaunchKernelGGL((trav_kernel<8>), dim3(t->nq), dim3(64), 0, st, t->P); break;
+            default: hipLaunchKernelGGL((trav_kernel<16>), dim3(t->nq), dim3(64), 0, st, t->P); break;
+        }
     }
-#define RH_K4G(LPR) trav4_kernel<LPR, true>
-#define RH_K4H(LPR) trav4_kernel<LPR, false>
-#define RH_K4B(LPR) trav4_kernel<LPR, false, false, true>
-#define RH_K4W(LPR) trav4_kernel<LPR, false, false, true, true>
-#define RH_K4GW(LPR) trav4_kernel<LPR, true, false, false, true>
-#define RH_K1H(LPR) trav_kernel<LPR>
-    if (t->use4 && t->wide && t->use_gt) { RH_TRAV_CASES(RH_K4GW, grid4) }
-    else if (t->use4 && t->wide) { RH_TRAV_CASES(RH_K4W, grid4) }
-    else if (t->use4 && t->use_gt) { RH_TRAV_CASES(RH_K4G, grid4) }
-    else if (t->use4 && t->use_bt) { RH_TRAV_CASES(RH_K4B, grid4) }
-    else if (t->use4) { RH_TRAV_CASES(RH_K4H, grid4) }
-    else { RH_TRAV_CASES(RH_K1H, t->nq) }
-#undef RH_K4B
-#undef RH_K4W
-#undef RH_K4GW
-#undef RH_K4G
-#undef RH_K4H
-#undef RH_K1H
-#undef RH_TRAV_CASES
     RH_HIP(hipGetLastError());
-    RH_HIP(hipEventRecord(t->ev1, idx->stream));
-    RH_HIP(hipStreamSynchronize(idx->stream));
+    RH_HIP(hipEventRecord(t->ev1, st));
+    return RADHIP_OK;
+}
+// ... and its end: wait for the stream, kernel time accumulated
+static int trav_collect(radhip_traversal *t) {
+    RH_HIP(hipStreamSynchronize(t->stream));
     float ms = 0.f;
     RH_HIP(hipEventElapsedTime(&ms, t->ev0, t->ev1));
 #ifdef RH_PROFILE
@@ -1088,13 +913,17 @@ static int trav_launch(radhip_traversal *t) {
     t->launches++;
     return RADHIP_OK;
 }
+static int trav_launch(radhip_traversal *t) {
+    RH_TRY(trav_enqueue(t));
+    return trav_collect(t);
+}
 
 // The grouped table filled one of its chunk positions (layout ids that pile onto one position: possible
 // only for an adversarial layout).  The batch has not returned anything yet: re-arm it with the per-slot
 // hash table, which has no such limit below its sized capacity, and run it again from the start.
 static int trav_fall_back_to_hash(radhip_traversal *t) {
-    if (t->wide) {   // the WIDE form has no per-slot hash variant: its fallback is the bucket table
-        const size_t bt_bytes = ((size_t)t->nq << (t->P.bt_log2 + 2)) * 4;
+    if (t->wide || t->P.slots) {   // the WIDE and the SLOT forms have no hash-table variant: their fallback is the bucket table
+        const size_t bt_bytes = ((size_t)t->sn << (t->P.bt_log2 + 2)) * 4;
         uint32_t *n_bt = nullptr;
         hipError_t e = hipMalloc((void **)&n_bt, bt_bytes);
         if (e != hipSuccess) { (void)hipGetLastError(); RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP,
@@ -1103,6 +932,7 @@ static int trav_fall_back_to_hash(radhip_traversal *t) {
         t->use_gt = false; t->use_bt = true;
         t->P.bt = n_bt; t->bt_bytes = bt_bytes; t->state_bytes += bt_bytes;
         t->epoch_max = (1u << (31u - t->P.bt_sbits)) - 1u;
+        t->P.epoch_first = 1u; t->P.epoch_max = t->epoch_max;
         t->fresh_tables = true;
         const double ms = t->kernel_ms;
         const uint64_t launches = t->launches;
@@ -1142,7 +972,7 @@ static int trav_grow_upper(radhip_traversal *t) {
     const uint32_t ut_log2 = P.ut_log2 + 2;
     const uint64_t pq_cap = P.scored_cap + ((uint64_t)1 << ut_log2);
     if (pq_cap >= 0xFFFFFFFFull) RH_FAIL(RADHIP_E_CAPACITY, "the key pool cannot grow any further");
-    const size_t ut_bytes = ((size_t)t->nq << ut_log2) * 8, pq_bytes = (size_t)t->nq * pq_cap * 8;
+    const size_t ut_bytes = ((size_t)t->sn << ut_log2) * 8, pq_bytes = (size_t)t->sn * pq_cap * 8;
     unsigned long long *n_ut = nullptr, *n_pq = nullptr;
     uint32_t *n_pl = nullptr;
     uint8_t *n_plv = nullptr;
@@ -1189,21 +1019,11 @@ static int trav_grow_upper(radhip_traversal *t) {
     return RADHIP_OK;
 }
 
-extern "C" int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, uint32_t *out_running) {
-    if (!t) RH_FAIL(RADHIP_E_INVALID, "null traversal");
-    radhip_index *idx = t->idx;
-    std::lock_guard<std::mutex> lk(idx->mu);
-    RH_HIP(hipSetDevice(idx->device));
-    // n_top, start_level, the table sizes and the layout were taken from the graph at create time: a
-    // traversal object does not survive an add() / load_graph() (the kernel would read freed arrays)
-    if (t->graph_gen != idx->graph_gen)
-        RH_FAIL(RADHIP_E_STATE, "the index changed since this traversal object was created: create a new one");
-    if (t->sharded) RH_FAIL(RADHIP_E_STATE, "a sharded traversal is stepped by radhip_shard_run / radhip_shard_step");
-    t->P.max_pops = max_pops;
-    const bool first_launch = t->launches == 0;
+// what a finished launch left: running / failed traversals; the capacity fallbacks re-arm and re-run a batch whose FIRST
+// launch hit a fixed-capacity structure (nothing of it has been returned to the caller yet)
+static int trav_after_launch(radhip_traversal *t, bool first_launch, uint32_t *out_running) {
     std::vector<TravHeader> hdr(t->nq);
     for (int attempt = 0;; ++attempt) {
-        RH_TRY(trav_launch(t));
         RH_HIP(hipMemcpy(hdr.data(), t->P.hdr, t->hdr_bytes, hipMemcpyDeviceToHost));
         uint32_t running = 0;
         int bad = 0;
@@ -1211,16 +1031,87 @@ extern "C" int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, ui
             if (hdr[i].status == 0) running++;  // status 3 (intermediate target reached) is parked, not running
             if (hdr[i].status < 0 && !bad) bad = hdr[i].status;
         }
-        if (bad == RADHIP_E_CAPACITY && first_launch && attempt < 4) {   // nothing was returned to the caller yet
+        if (bad == RADHIP_E_CAPACITY && first_launch && attempt < 4) {
             if (t->use_gt) RH_TRY(trav_fall_back_to_hash(t));
             else RH_TRY(trav_grow_upper(t));
+            RH_TRY(trav_launch(t));
             continue;
         }
         if (out_running) *out_running = running;
         if (bad) RH_FAIL(bad, "traversal state overflowed a fixed-capacity device structure (status %d)", bad);
+        if (t->P.slots && running) RH_FAIL(RADHIP_E_STATE, "%u traversals of a per-row-state batch did not run to completion", running);
         return RADHIP_OK;
     }
 }
+
+static int trav_check_runnable(radhip_traversal *t, uint64_t max_pops) {
+    radhip_index *idx = t->idx;
+    // n_top, start_level, the table sizes and the layout were taken from the graph at create time: a
+    // traversal object does not survive an add() / load_graph() (the kernel would read freed arrays)
+    if (t->graph_gen != idx->graph_gen)
+        RH_FAIL(RADHIP_E_STATE, "the index changed since this traversal object was created: create a new one");
+    if (t->sharded) RH_FAIL(RADHIP_E_STATE, "a sharded traversal is stepped by radhip_shard_run / radhip_shard_step");
+    if (t->in_flight) RH_FAIL(RADHIP_E_STATE, "the traversal object has a launch in flight: radhip_traversal_finish first");
+    if (t->P.slots && max_pops) RH_FAIL(RADHIP_E_STATE, "a batch with per-row state (RADHIP_TRAV_SLOTS) runs to completion: max_pops must be 0");
+    return RADHIP_OK;
+}
+
+extern "C" int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, uint32_t *out_running) {
+    if (!t) RH_FAIL(RADHIP_E_INVALID, "null traversal");
+    radhip_index *idx = t->idx;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_HIP(hipSetDevice(idx->device));
+    RH_TRY(trav_check_runnable(t, max_pops));
+    t->P.max_pops = max_pops;
+    const bool first_launch = t->launches == 0;
+    RH_TRY(trav_launch(t));
+    return trav_after_launch(t, first_launch, out_running);
+}
+
+// ---- launches that do not wait (round 4).  A launch of a batch ends with its longest traversals running alone (~130 ms
+// whatever its size: profiles/r03/README.md §8).  Two objects on two streams (RADHIP_TRAV_OWN_STREAM), each with its own
+// rows' state and its own outputs: the next batch's wavefronts start as the last ones of this batch leave the device, and
+// the tail is paid once per run instead of once per batch.  start = re-armed batch -> kernel enqueued; finish = wait +
+// everything radhip_traversal_run does after its launch.
+extern "C" int radhip_traversal_start(radhip_traversal_t *t) {
+    if (!t) RH_FAIL(RADHIP_E_INVALID, "null traversal");
+    radhip_index *idx = t->idx;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_HIP(hipSetDevice(idx->device));
+    RH_TRY(trav_check_runnable(t, 0));
+    t->P.max_pops = 0;
+    t->first_pending = t->launches == 0;
+    RH_TRY(trav_enqueue(t));
+    t->in_flight = true;
+    return RADHIP_OK;
+}
+extern "C" int radhip_traversal_finish(radhip_traversal_t *t, uint32_t *out_running) {
+    if (!t) RH_FAIL(RADHIP_E_INVALID, "null traversal");
+    radhip_index *idx = t->idx;
+    if (!t->in_flight) RH_FAIL(RADHIP_E_STATE, "no launch in flight");
+    RH_HIP(hipSetDevice(idx->device));
+    // the wait happens outside the index lock: another object's start must be able to get in meanwhile
+    {
+        const hipError_t e = hipStreamSynchronize(t->stream);
+        if (e != hipSuccess) { std::lock_guard<std::mutex> lk(idx->mu); t->in_flight = false; RH_FAIL(RADHIP_E_HIP, "the traversal's stream failed: %s", hipGetErrorString(e)); }
+    }
+    std::lock_guard<std::mutex> lk(idx->mu);
+    t->in_flight = false;
+    RH_TRY(trav_collect(t));
+    return trav_after_launch(t, t->first_pending, out_running);
+}
+// milliseconds from the start of `from`'s last launch to the end of `to`'s last launch (both finished; events on the
+// device's clock, whatever streams they were recorded on): the busy interval of a run of overlapping launches
+extern "C" int radhip_traversal_elapsed_between(const radhip_traversal_t *from, const radhip_traversal_t *to, double *out_ms) {
+    if (!from || !to || !out_ms) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (from->in_flight || to->in_flight) RH_FAIL(RADHIP_E_STATE, "a launch is still in flight");
+    float ms = 0.f;
+    RH_HIP(hipEventElapsedTime(&ms, from->ev0, to->ev1));
+    *out_ms = ms;
+    return RADHIP_OK;
+}
+// rows whose state the batch shares (0 = state per traversal)
+extern "C" uint32_t radhip_traversal_slots(const radhip_traversal_t *t) { return t ? t->P.slots : 0; }
 
 extern "C" int radhip_traversal_stats(const radhip_traversal_t *t, radhip_trav_stats_t *out) {
     if (!t || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
@@ -1291,11 +1182,11 @@ extern "C" int radhip_traversal_result_hashes(const radhip_traversal_t *t, uint3
     unsigned long long *d = nullptr;
     RH_HIP(hipMalloc((void **)&d, (size_t)count * 8));
     int rc = RADHIP_OK;
-    if (hipMemsetAsync(d, 0, (size_t)count * 8, idx->stream) != hipSuccess) rc = RADHIP_E_HIP;
+    if (hipMemsetAsync(d, 0, (size_t)count * 8, t->stream) != hipSuccess) rc = RADHIP_E_HIP;
     if (rc == RADHIP_OK) {
-        hipLaunchKernelGGL(result_hash_kernel, dim3(count), dim3(256), 0, idx->stream, t->P.scored, t->P.scored_cap, t->P.hdr, first, d);
-        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d, (size_t)count * 8, hipMemcpyDeviceToHost, idx->stream) != hipSuccess ||
-            hipStreamSynchronize(idx->stream) != hipSuccess) rc = RADHIP_E_HIP;
+        hipLaunchKernelGGL(result_hash_kernel, dim3(count), dim3(256), 0, t->stream, t->P.scored, t->P.scored_cap, t->P.hdr, first, d);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d, (size_t)count * 8, hipMemcpyDeviceToHost, t->stream) != hipSuccess ||
+            hipStreamSynchronize(t->stream) != hipSuccess) rc = RADHIP_E_HIP;
     }
     (void)hipFree(d);
     if (rc != RADHIP_OK) radhip_set_error("radhip_traversal_result_hashes failed");
@@ -1329,6 +1220,7 @@ extern "C" int radhip_traversal_kernel_time(const radhip_traversal_t *t, double 
 extern "C" uint64_t radhip_traversal_state_bytes(const radhip_traversal_t *t) { return t ? t->state_bytes : 0; }
 
 extern "C" int radhip_traversal_set_targets(radhip_traversal_t *t, const uint64_t *targets) {
+    if (t && t->P.slots) RH_FAIL(RADHIP_E_STATE, "a batch with per-row state (RADHIP_TRAV_SLOTS) runs to completion: it has no parked targets");
     if (!t || !targets) RH_FAIL(RADHIP_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(t->idx->mu);
     RH_HIP(hipSetDevice(t->idx->device));
@@ -1373,45 +1265,7 @@ __global__ void debug_keys_kernel(const uint32_t *a, const uint32_t *o, const ui
     }
 }
 
-// test hook: trav4_kernel's staging sort (t4_sort256: register-resident flip-form bitonic network, one wavefront)
-__global__ __launch_bounds__(64) void debug_sort_kernel(const unsigned long long *in, const uint32_t *counts, unsigned long long *out) {
-    __shared__ unsigned long long S[256];
-    const uint32_t lane = threadIdx.x, n = counts[blockIdx.x];
-    for (uint32_t i = lane; i < 256u; i += 64u) S[i] = i < n ? in[(uint64_t)blockIdx.x * 256u + i] : 0x1234ull;   // junk beyond n: the sort must not read it
-    WSYNC();
-    t4_sort256(S, n, lane);
-    WSYNC();
-    for (uint32_t i = lane; i < T4_S; i += 64u) out[(uint64_t)blockIdx.x * 256u + i] = S[i];
-}
-
-extern "C" int radhip_debug_sort_staging(radhip_index_t *idx, const uint64_t *keys, const uint32_t *counts, uint32_t batches,
-                                         uint64_t *out) {
-    if (!idx || !keys || !counts || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
-    if (batches == 0) return RADHIP_OK;
-    for (uint32_t b = 0; b < batches; ++b) if (counts[b] > T4_S) RH_FAIL(RADHIP_E_INVALID, "a staging buffer holds at most %u keys", T4_S);
-    std::lock_guard<std::mutex> lk(idx->mu);
-    RH_TRY(rh_ensure_device(idx));
-    unsigned long long *din = nullptr, *dout = nullptr;
-    uint32_t *dc = nullptr;
-    int rc = RADHIP_OK;
-    const size_t bytes = (size_t)batches * 256 * 8;
-    if (hipMalloc((void **)&din, bytes) != hipSuccess || hipMalloc((void **)&dout, bytes) != hipSuccess ||
-        hipMalloc((void **)&dc, (size_t)batches * 4) != hipSuccess) rc = RADHIP_E_NOMEM;
-    if (rc == RADHIP_OK && (hipMemcpy(din, keys, bytes, hipMemcpyHostToDevice) != hipSuccess ||
-                            hipMemcpy(dc, counts, (size_t)batches * 4, hipMemcpyHostToDevice) != hipSuccess ||
-                            hipMemsetAsync(dout, 0, bytes, idx->stream) != hipSuccess)) rc = RADHIP_E_HIP;
-    if (rc == RADHIP_OK) {
-        hipLaunchKernelGGL(debug_sort_kernel, dim3(batches), dim3(64), 0, idx->stream, din, dc, dout);
-        if (hipStreamSynchronize(idx->stream) != hipSuccess) rc = RADHIP_E_HIP;
-        else if (hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = RADHIP_E_HIP;
-    }
-    if (din) (void)hipFree(din);
-    if (dout) (void)hipFree(dout);
-    if (dc) (void)hipFree(dc);
-    if (rc != RADHIP_OK) radhip_set_error("radhip_debug_sort_staging failed (%d)", rc);
-    return rc;
-}
-extern "C" uint32_t radhip_debug_staging_capacity(void) { return T4_S; }
+extern "C" uint32_t radhip_debug_staging_capacity(void) { return rh_trav4_staging_capacity(); }
 
 extern "C" int radhip_debug_device_keys(radhip_index_t *idx, const uint32_t *a, const uint32_t *o, const uint32_t *slot,
                                         const uint32_t *level, uint64_t n, uint64_t *out_keys) {
@@ -1464,15 +1318,8 @@ static int trav_forced_kernel() {
 static int trav_capacity_of(radhip_index *idx, bool use4, uint32_t *out) {
     int per_cu = 0;
     hipError_t e;
-    if (use4) {
-        switch (idx->lpr) {
-            case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<1, false>, 64, 0); break;
-            case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<2, false>, 64, 0); break;
-            case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<4, false>, 64, 0); break;
-            case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<8, false>, 64, 0); break;
-            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav4_kernel<16, false>, 64, 0); break;
-        }
-    } else
+    if (use4) { RH_TRY(rh_trav4_occupancy((int)idx->lpr, &per_cu)); e = hipSuccess; }
+    else
     switch (idx->lpr) {
         case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav_kernel<1>, 64, 0); break;
         case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav_kernel<2>, 64, 0); break;

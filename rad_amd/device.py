@@ -221,15 +221,20 @@ assert _TRAV_STATS_DTYPE.itemsize == C.sizeof(_lib.TravStats)
 class DeviceTraversal:
     """nq independent RAD traversals, Tanimoto-scored, state in HBM (radhip_traversal_t)."""
 
-    def __init__(self, index: DeviceIndex, queries: np.ndarray, n_to_score: int, log_pops: bool = False):
+    def __init__(self, index: DeviceIndex, queries: np.ndarray, n_to_score: int, log_pops: bool = False,
+                 slots: bool = False, own_stream: bool = False):
+        """slots: the heavy state (tables, queue pools) once per resident row of the kernel instead of once per traversal —
+        such a batch runs to completion (no max_pops, no set_targets); own_stream: a HIP stream of the object's own, so
+        that start() / finish() of two objects overlap."""
         self._L = _lib.lib()
         self.index = index
         q = _lib.as_rows(queries, index.row_bytes, "queries")
         self.nq = q.shape[0]
         self.n_to_score = int(n_to_score)
         self._h = C.c_void_p()
-        check(self._L.radhip_traversal_create(index._h, ptr(q), self.nq, self.n_to_score,
-                                              _lib.TRAV_LOG_POPS if log_pops else 0, C.byref(self._h)))
+        flags = (_lib.TRAV_LOG_POPS if log_pops else 0) | (_lib.TRAV_SLOTS if slots else 0) | (_lib.TRAV_OWN_STREAM if own_stream else 0)
+        check(self._L.radhip_traversal_create(index._h, ptr(q), self.nq, self.n_to_score, flags, C.byref(self._h)))
+        self.slots = int(self._L.radhip_traversal_slots(self._h))   # 0: state per traversal (flag not given, or not applicable)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -254,6 +259,21 @@ class DeviceTraversal:
         running = C.c_uint32(0)
         check(self._L.radhip_traversal_run(self._h, max_pops, C.byref(running)))
         return running.value
+
+    def start(self) -> None:
+        """enqueue the launch of the (re-armed) batch and return; finish() waits for it"""
+        check(self._L.radhip_traversal_start(self._h))
+
+    def finish(self) -> int:
+        running = C.c_uint32(0)
+        check(self._L.radhip_traversal_finish(self._h, C.byref(running)))
+        return running.value
+
+    def elapsed_to(self, other: "DeviceTraversal") -> float:
+        """ms on the device's clock from the start of this object's last launch to the end of `other`'s last launch"""
+        ms = C.c_double(0)
+        check(self._L.radhip_traversal_elapsed_between(self._h, other._h, C.byref(ms)))
+        return ms.value
 
     def stats(self) -> TraversalStats:
         arr = (_lib.TravStats * self.nq)()

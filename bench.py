@@ -51,6 +51,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 RANDOM_LINE_PEAK_G = 38.2   # G random 128-B line reads per second at a 64 GiB footprint, measured (profiles/r03/latency_footprint.log)
+# request rates of the memory side by shape, 32 GiB footprint (scripts/probe_request_size.hip, profiles/r04/probe_request_size.md)
+READ_LINES_G = 44.0         # random 128-B line reads: 38.4 (16 B per lane, 64 lines per instruction) .. 48.5 (<= 32 lines per instruction)
+PARTIAL_WRITES_G = 21.9     # random writes of 4 .. 32 B (one 32-B request each)
+FULL_WRITES_G = 49.5        # random full 64-B writes
 METRIC = "neighbor-expansions/sec (1024-bit Tanimoto) + HBM GB/s vs roofline"
 
 
@@ -70,15 +74,29 @@ def parse_args():
     ap.add_argument("--graph", choices=["built", "synthetic"], default="built",
                     help="adjacency: an HNSW graph built on the GPU by Index.add (default) or the closed-form "
                          "generator (corpus mode 1 only; set up in 20 ms)")
-    ap.add_argument("--expansion-add", type=int, default=64, help="expansion_add of the built graph")
+    ap.add_argument("--expansion-add", type=int, default=400,
+                    help="expansion_add of the built graph: 400 = the reference README's value (README.md:52), the headline graph since round 4 "
+                         "(162 s for 100M rows); rounds 1-3 benched a graph built with 64 (20 s), kept as the labelled secondary leg")
+    ap.add_argument("--secondary-expansion-add", type=int, default=64,
+                    help="N = 1: a second, shorter leg on a graph built with this expansion_add (0 = skip)")
+    ap.add_argument("--graph-cache", default="", help="profiling sessions: .npz the built graph is saved to / loaded from, so that every "
+                                                       "rocprofv3 pass does not build it again (the graph is the same; only setup time changes)")
+    ap.add_argument("--no-overlap", action="store_true", help="one traversal object, one launch after the other (A/B against the two-stream pipeline)")
+    ap.add_argument("--no-kernel-legs", action="store_true", help="skip the K1 scan / K2 gather / top-k measurements of the N = 1 line")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the BASELINE configs[1] / configs[4] legs of the N = 1 line")
+    ap.add_argument("--config-budget-s", type=float, default=150.0, help="wall-clock budget of the configs legs together")
     ap.add_argument("--table", choices=["auto", "hash", "group"], default="auto",
                     help="visited/scored table of the traversal kernel (auto = the library's default, the per-slot hash table; "
                          "group = the grouped table over the graph-locality layout, measured slower: profiles/r02)")
     ap.add_argument("--no-reference-corpus", action="store_true", help="skip the round-1 corpus leg (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work the cpu_baseline sample should take at least")
-    ap.add_argument("--mode", choices=["sharded", "replicas"], default="replicas", help="which N > 1 leg `value` reports (both always run)")
-    ap.add_argument("--sharded-timeout", type=float, default=420.0,
+    ap.add_argument("--mode", choices=["sharded", "replicas", "peer"], default="replicas",
+                    help="which N > 1 leg `value` reports: replicas (every GPU holds the corpus), sharded (rows sharded, RCCL all-gather per frontier "
+                         "step), peer (rows sharded, every rank maps the peers' shards into one address range and runs the single-GPU kernel "
+                         "over xGMI reads: no collective); in replicas mode the other two run as side legs")
+    ap.add_argument("--no-peer-leg", action="store_true", help="skip the peer-mapped side leg of an N > 1 replicas run")
+    ap.add_argument("--sharded-timeout", type=float, default=300.0,
                     help="seconds the sharded leg may take before the line is printed without it (a hung collective must not cost the run)")
     ap.add_argument("--sharded-nq", type=int, default=65536,
                     help="traversals per rank and batch of the sharded leg (0.8 MB each for the scored list; the slots hold the rest)")
@@ -172,12 +190,25 @@ def build_index(args, mode, device, layout=True):
     if args.graph == "synthetic" and mode == 1:
         idx.synth_graph(seed=777)
     else:
-        # the rows are resident already (generated on the device): they are linked where they are, no host copy
-        # of the corpus (radhip_index_link_resident == radhip_index_add of the same rows, tests/test_gpu_sharded.py)
-        t_build = time.perf_counter()
-        idx.link_resident(seed=777, max_batch=16384)
-        t_build = time.perf_counter() - t_build
-        note(f"graph built in {t_build:.1f} s")
+        cache = getattr(args, "graph_cache", "")
+        cache = f"{cache}.n{n}.m{M}.ef{args.expansion_add}.mode{mode}.npz" if cache else ""
+        if cache and os.path.exists(cache):
+            z = np.load(cache)
+            idx.load_graph(z["levels"], z["adj0"], z["upper_row"], z["adjU"], int(z["max_level"]), int(z["entry"]))
+            t_build = float(z["t_build"])
+            note(f"graph loaded from {cache} (built in {t_build:.1f} s when it was made)")
+        else:
+            # the rows are resident already (generated on the device): they are linked where they are, no host copy
+            # of the corpus (radhip_index_link_resident == radhip_index_add of the same rows, tests/test_gpu_sharded.py)
+            t_build = time.perf_counter()
+            idx.link_resident(seed=777, max_batch=16384)
+            t_build = time.perf_counter() - t_build
+            note(f"graph built in {t_build:.1f} s")
+            if cache:
+                levels, adj0, upper_row, adjU = idx.read_graph()
+                inf = idx.info()
+                np.savez(cache, levels=levels, adj0=adj0, upper_row=upper_row, adjU=adjU, max_level=int(inf.max_level), entry=int(inf.entry), t_build=t_build)
+                note(f"graph saved to {cache}")
     info = None
     if layout and args.table == "group":
         info = idx.optimize_layout()
@@ -189,51 +220,90 @@ def query_batches(idx, n_batches, nq, n, seed):
     return [idx.read_vectors(int(qrng.integers(0, n - nq)), nq) for _ in range(n_batches)]
 
 
-def run_traversal_leg(args, idx, batches, steps, warmup, barrier):
-    """`steps` timed steps of the single-GPU hot path on this rank's index.  Returns a dict of sums and the
-    per-step kernel times."""
+def union_ms(intervals):
+    """length of the union of [start, end] intervals (ms)"""
+    tot, cur_s, cur_e = 0.0, None, None
+    for s_, e_ in sorted(intervals):
+        if cur_e is None or s_ > cur_e:
+            if cur_e is not None:
+                tot += cur_e - cur_s
+            cur_s, cur_e = s_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    return tot + ((cur_e - cur_s) if cur_e is not None else 0.0)
+
+
+def run_traversal_leg(args, idx, batches, steps, warmup, barrier, overlap=True):
+    """`steps` timed steps of the single-GPU hot path on this rank's index.  One step = one batch: re-arm (query upload; the
+    rows' epochs make table reuse free) + one launch of the traversal kernel to completion of the batch.  The traversal
+    state lives per resident ROW of the kernel (RADHIP_TRAV_SLOTS) and two objects on two streams take the batches in turn,
+    so that the next batch's wavefronts start while the last traversals of this one still run (a launch ends with its
+    longest traversals running alone: ~130 ms whatever its size).  The pipeline is empty before the clock starts and is
+    drained before it stops: exactly `steps` batches are started and finished inside the timed region."""
     from rad_amd.device import DeviceTraversal
-    trav = DeviceTraversal(idx, batches[0], args.n_to_score)
+    n_obj = 2 if (overlap and steps + warmup > 1) else 1
+    objs = [DeviceTraversal(idx, batches[0], args.n_to_score, slots=True, own_stream=n_obj > 1) for _ in range(n_obj)]
+    note(f"traversal state for {n_obj} x {objs[0].nq} traversals allocated ({sum(o.state_bytes() for o in objs) / 1e9:.1f} GB, kernel {objs[0].kernel}, "
+         f"table {objs[0].table}, {objs[0].slots or objs[0].nq} rows' worth of tables)")
+    acc = {"pops": 0, "evals": 0, "nbrs": 0, "k_ms": [], "iv": [], "last": None, "last_obj": None}
 
-    def step(b):
-        trav.reset(batches[b])
-        running = trav.run(0)
-        assert running == 0
-        ms, launches = trav.kernel_time()
-        st = trav.stats()
-        return ms, launches, st
+    def collect(o, timed):
+        assert o.finish() == 0
+        if not timed:
+            return
+        st = o.stats()
+        ms, launches = o.kernel_time()
+        acc["k_ms"].append(ms / max(launches, 1))
+        acc["iv"].append(o.launch_interval())
+        acc["pops"] += int(st.n_pops.sum()); acc["evals"] += int(st.n_scored.sum()); acc["nbrs"] += int(st.n_nbr.sum())
+        acc["last"], acc["last_obj"] = st, o
 
-    note(f"traversal state for {trav.nq} traversals allocated ({trav.state_bytes() / 1e9:.1f} GB, kernel {trav.kernel}, table {trav.table})")
-    for w in range(warmup):
-        step(w)
+    def pipeline(first, count, timed):
+        flying = []
+        for s_ in range(count):
+            o = objs[s_ % n_obj]
+            if o in flying:
+                collect(o, timed); flying.remove(o)
+            o.reset(batches[first + s_])
+            o.start(); flying.append(o)
+        for o in flying:
+            collect(o, timed)
+
+    pipeline(0, warmup, False)
     note("warm-up done")
     barrier()
     t0 = time.perf_counter()
-    k_ms, k_launches, pops, evals, nbrs = [], 0, 0, 0, 0
-    last = None
-    for s in range(steps):
-        ms, launches, st = step(warmup + s)
-        k_ms.append(ms / max(launches, 1))
-        k_launches += launches
-        pops += int(st.n_pops.sum()); evals += int(st.n_scored.sum()); nbrs += int(st.n_nbr.sum())
-        last = st
+    pipeline(warmup, steps, True)
     barrier()
     elapsed = time.perf_counter() - t0
     note(f"{steps} timed steps done ({elapsed / max(steps, 1) * 1e3:.0f} ms each)")
-    out = {"elapsed": elapsed, "pops": pops, "evals": evals, "nbrs": nbrs, "k_ms": k_ms, "launches": k_launches,
-           "kernel": trav.kernel, "table": trav.table, "state_bytes": trav.state_bytes(), "last_stats": last,
-           "last_hashes": trav.result_hashes(0, trav.nq),
+    last, lo = acc["last"], acc["last_obj"]
+    out = {"elapsed": elapsed, "pops": acc["pops"], "evals": acc["evals"], "nbrs": acc["nbrs"], "k_ms": acc["k_ms"], "launches": len(acc["k_ms"]),
+           "busy_ms": union_ms(acc["iv"]), "objects": n_obj, "slots": objs[0].slots,
+           "kernel": lo.kernel, "table": lo.table, "state_bytes": sum(o.state_bytes() for o in objs), "last_stats": last,
+           "last_hashes": lo.result_hashes(0, lo.nq),
            "remids": float(last.n_remid.mean()), "repivots": float(last.n_repivot.mean()), "flushes": float(last.n_flush.mean())}
-    trav.close()
+    for o in objs:
+        o.close()
     return out
 
 
 def roofline_of(leg, B):
-    alg = (leg["evals"] * (B + 4) + leg["pops"] * 4) / max(leg["launches"], 1)
+    """Algorithmic bytes (B + 4 per evaluation, 4 per expansion) over the time the device ran the traversal kernel.
+    With two objects the launches of consecutive batches overlap (the next batch's wavefronts fill the device while the last
+    traversals of this one finish), so `achieved` = ALL timed launches' bytes / the UNION of their HIP-event intervals —
+    summed work over the time the kernel was on the device; `avg_launch_ms` is still the mean start-to-end duration of one launch
+    (what rocprofv3 --kernel-trace --stats reports per kernel: it contains the time a launch shares the device with its neighbour)."""
+    alg_total = leg["evals"] * (B + 4) + leg["pops"] * 4
+    alg = alg_total / max(leg["launches"], 1)
     avg_ms = float(np.mean(leg["k_ms"]))
-    ach = alg / (avg_ms * 1e-3) / 1e9
+    busy = leg["busy_ms"] if leg.get("busy_ms") else avg_ms * leg["launches"]
+    ach = alg_total / (busy * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": leg["kernel"], "table": leg["table"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms,
+            "kernel_busy_ms": busy, "kernel_busy_ms_per_launch": busy / max(leg["launches"], 1),
+            "accounting": "achieved = algorithmic bytes of all timed launches / union of their HIP-event intervals (launches of consecutive batches overlap on two streams)",
+            "achieved_by_avg_launch_duration": alg / (avg_ms * 1e-3) / 1e9,
             "launch_ms_median": pctl(leg["k_ms"], 50), "launch_ms_p10": pctl(leg["k_ms"], 10), "launch_ms_p90": pctl(leg["k_ms"], 90),
             "launches": leg["launches"]}
 
@@ -249,6 +319,87 @@ def recall_of(idx, Q, k=10, ef=128):
     check(_lib.lib().radhip_search(idx._h, ptr(Q), nq, k, ef, ptr(s), ptr(a), ptr(o), ptr(cnt), None, None))
     es, _ea, _eo, _ec = idx.topk(Q, k)
     return float(np.mean([len(set(s[i]) & set(es[i])) / k for i in range(nq)]))
+
+
+def kernel_legs(idx, n, B):
+    """The other kernels of the path on the SAME resident corpus, each by HIP events on the library's stream (radhip_last_kernel_ms):
+    K1 scan (query x all rows, N x B bytes per pass), K2 gather (random 128-B rows, B + 4 per pair) and the exact top-k scan
+    (wall time: it is several kernels).  SURVEY.md §8d; VERDICT r03 #3(i)."""
+    from rad_amd import _lib
+    L = _lib.lib()
+    out = {}
+    q = idx.read_vectors(7, 8)
+    chunk = 25_000_000          # (and, or) of every row come back to the host: bound the buffers
+    for nq in (1, 8):
+        ms = 0.0
+        for f in range(0, n, chunk):
+            c = min(chunk, n - f)
+            idx.scan(q[:nq], f, c)
+            ms += L.radhip_last_kernel_ms()
+        gbs = n * B / (ms * 1e-3) / 1e9
+        out[f"scan_{nq}q"] = {"ms": ms, "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS, "G_evals_per_s": n * nq / (ms * 1e-3) / 1e9,
+                              "bytes": "rows read once per pass (N x B); + 8 B per (query, row) written"}
+    rng = np.random.default_rng(0)
+    m = 20_000_000
+    slots = rng.integers(0, n, m).astype(np.uint32)
+    off = (np.arange(5, dtype=np.uint64) * (m // 4)).astype(np.uint64); off[-1] = m
+    best = None
+    for _ in range(2):
+        idx.gather(q[:4], slots, off)
+        ms = L.radhip_last_kernel_ms()
+        best = ms if best is None else min(best, ms)
+    gbs = m * (B + 4) / (best * 1e-3) / 1e9
+    out["gather"] = {"ms": best, "pairs": m, "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS, "G_pairs_per_s": m / (best * 1e-3) / 1e9,
+                     "bytes": "B + 4 per (query, slot) pair: a random 128-B row and its slot id"}
+    Q = idx.read_vectors(1234, 8)
+    idx.topk(Q, 10)
+    t0 = time.perf_counter(); s_, _a, _o, _c = idx.topk(Q, 10); dt = time.perf_counter() - t0
+    gbs = n * B / dt / 1e9
+    out["topk_8q_k10"] = {"ms": dt * 1e3, "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS, "G_evals_per_s": 8 * n / dt / 1e9,
+                          "self_is_nearest": bool((s_[:, 0] == np.arange(1234, 1242)).all()),
+                          "bytes": "rows read once for the 8 queries of a pass (N x B); wall time incl. query upload / result download"}
+    return out
+
+
+def config_legs(args, device):
+    """BASELINE.json configs[1] and configs[4] on the driver's clock, behind a time budget: small enough to build
+    their graphs here (GPU insert kernels, expansion_add as the config says), traversed by the kernel the library picks."""
+    from rad_amd import _lib
+    from rad_amd.device import DeviceIndex, DeviceTraversal
+    t_start = time.perf_counter()
+    out = {}
+
+    def one(tag, n, ndim, M, ef, nq, nts, steps=2):
+        if time.perf_counter() - t_start > args.config_budget_s:
+            out[tag] = {"skipped": "time budget"}
+            return
+        idx = DeviceIndex(ndim, M, 2 * M, ef, device=device)
+        idx.synth_vectors(n, seed=20260101, mode=2)
+        t0 = time.perf_counter(); idx.link_resident(seed=777, max_batch=16384); tb = time.perf_counter() - t0
+        Bc = idx.info().row_stride
+        rng = np.random.default_rng(7)
+        bs = [idx.read_vectors(int(rng.integers(0, n - nq)), nq) for _ in range(steps + 1)]
+        a = argparse.Namespace(**vars(args)); a.n_to_score = nts
+        leg = run_traversal_leg(a, idx, bs, steps, 1, lambda: None, overlap=not args.no_overlap)
+        rf = roofline_of(leg, Bc)
+        q8 = idx.read_vectors(3, 8)
+        idx.scan(q8, 0, min(n, 8_000_000)); idx.scan(q8, 0, min(n, 8_000_000))
+        sms = _lib.lib().radhip_last_kernel_ms()
+        out[tag] = {"rows": n, "ndim": ndim, "connectivity": M, "expansion_add": ef, "graph_build_s": tb, "traversals_per_step": nq, "n_to_score": nts,
+                    "steps": steps, "value": leg["pops"] / leg["elapsed"], "unit": "expansions/s", "evals_per_expansion": leg["evals"] / max(leg["pops"], 1),
+                    "kernel": leg["kernel"], "table": leg["table"], "roofline_frac": rf["frac"], "roofline_achieved_gbs": rf["achieved"],
+                    "avg_launch_ms": rf["avg_launch_ms"], "graph_recall_at_10_ef128": recall_of(idx, bs[-1][:64]),
+                    "scan_8q_GB/s": min(n, 8_000_000) * Bc / (sms * 1e-3) / 1e9}
+        idx.close()
+        note(f"config leg {tag}: {out[tag]['value'] / 1e9:.3f} G expansions/s, frac {rf['frac']:.3f}")
+
+    # configs[1]: 1M random 1024-bit fingerprints, connectivity 8, single MI355X (Tanimoto kernels; traversal to 100k)
+    one("c1_1M_1024bit_m8", 1_000_000, 1024, 8, 64, 16384, 100_000)
+    # configs[4]: 2048-bit fingerprints, connectivity 32, expansion_add 400 (2M rows: what builds inside the budget)
+    one("c4_2M_2048bit_m32_ef400", 2_000_000, 2048, 32, 400, 16384, 20_000)
+    # the reference notebook's shape (examples/DUDEZ_example.ipynb:165-166): connectivity 16, expansion_add 400
+    one("notebook_shape_2M_1024bit_m16_ef400", 2_000_000, 1024, 16, 400, 32768, 20_000)
+    return out
 
 
 def cpu_baseline(idx, queries, gpu_stats, args, gpu_hashes=None):
@@ -445,6 +596,70 @@ def drive_shards(args, grp, rank, world, idx, first, count, Qall, comms, barrier
     for sh in shards:
         sh.close()
     return res
+
+
+def peer_index(args, grp, rank, world, local_rank, graph_from=None):
+    """This rank's view of a corpus whose ROWS are sharded over the ranks: its own shard generated on the device, the peers' shards
+    mapped behind it (dmabuf descriptors over a Unix socket, xGMI reads), one contiguous range — the single-GPU kernels run on it
+    unchanged.  The graph: copied device to device from `graph_from` (an index of this rank that has it), else the closed-form one."""
+    from rad_amd.device import DeviceIndex
+    from rad_amd.rendezvous import exchange_fds
+    n, M = args.n, args.connectivity
+    pidx = DeviceIndex(args.ndim, M, 2 * M, args.expansion_add, device=local_rank)
+    rps = pidx.peer_create(rank, world, n)
+    pidx.peer_fill_synth(seed=20260101, mode=args.corpus_mode)
+    fd = pidx.peer_export()
+    fds = exchange_fds(rank, world, fd, f"bench-{os.environ.get('MASTER_PORT', '0')}-{args.n}")
+    for p_ in range(world):
+        if p_ != rank:
+            pidx.peer_import(p_, fds[p_])
+            os.close(fds[p_])
+    os.close(fd)
+    grp.barrier()                      # every rank has imported what it needs before anybody can tear a shard down
+    pidx.peer_seal()
+    if graph_from is not None:
+        pidx.copy_graph_from(graph_from)
+    else:
+        pidx.synth_graph(seed=777)
+    return pidx, rps
+
+
+def run_peer_leg(args, full, grp, rank, world, local_rank, barrier):
+    """BASELINE's row partitioning at the single-GPU kernel's rate: rows sharded over the ranks, every rank maps all shards and
+    traverses with the unchanged kernel.  Parity: the same queries on this rank's whole-corpus index (`full`, when it has one)
+    must give the same scored lists (64-bit hashes of all of them)."""
+    from rad_amd.device import DeviceTraversal
+    pidx, rps = peer_index(args, grp, rank, world, local_rank, graph_from=full if args.graph == "built" else None)
+    steps = min(args.steps, 4)
+    batches = query_batches(pidx, 1 + steps, args.nq, args.n, 777 + rank)
+    good = tot = 0
+    if full is not None:
+        ns = min(512, args.nq)
+        a_ = DeviceTraversal(pidx, batches[0][:ns], args.n_to_score); a_.run(0)
+        b_ = DeviceTraversal(full, batches[0][:ns], args.n_to_score); b_.run(0)
+        good, tot = int((a_.result_hashes() == b_.result_hashes()).sum()), ns
+        a_.close(); b_.close()
+    leg = run_traversal_leg(args, pidx, batches, steps, 1, barrier, overlap=not args.no_overlap)
+    res = {"pops": leg["pops"], "evals": leg["evals"], "elapsed": leg["elapsed"], "steps": steps, "rows_per_shard": rps,
+           "index_bytes": int(pidx.info().device_bytes), "parity_ok": good, "parity_n": tot, "state_bytes": leg["state_bytes"],
+           "busy_ms": leg["busy_ms"], "launches": leg["launches"]}
+    pidx.close()
+    return res
+
+
+def peer_report(args, grp, pr, world, B):
+    tot = grp.allreduce([pr["pops"], pr["evals"], pr["parity_ok"], pr["parity_n"]], "sum")
+    el = float(grp.allreduce([pr["elapsed"]], "max")[0])
+    idxb = grp.allgather_obj(pr["index_bytes"])
+    alg = (float(tot[1]) * (B + 4) + float(tot[0]) * 4) / world
+    return {"value": float(tot[0]) / el, "unit": "expansions/s", "ms_per_step": el / pr["steps"] * 1e3, "steps": pr["steps"], "warmup": 1,
+            "evals_per_s": float(tot[1]) / el, "rows_per_shard": pr["rows_per_shard"], "index_bytes_per_rank": [int(b) for b in idxb],
+            "parity_vs_whole_corpus_index": f"{int(tot[2])}/{int(tot[3])}" if tot[3] else None,
+            "roofline_frac_per_gpu": alg / el / 1e9 / HBM_PEAK_GBS,
+            "remote_share_of_row_reads": (world - 1) / world,
+            "partitioning": f"rows sharded by contiguous slot range ({pr['rows_per_shard']} per GPU: ceil(N / G) rounded up to the 2-MiB granule), adjacency replicated; "
+                            "every rank maps all shards into one virtual range (HIP VMM, dmabuf descriptors) and runs the single-GPU traversal kernel unchanged: "
+                            "remote rows are 128-B reads over xGMI, no collective, no lock step; results bit-identical to one GPU by construction"}, int(tot[2]), int(tot[3])
 
 
 def run_sharded_leg(args, idx, grp, rank, world, local_rank, barrier):
@@ -668,24 +883,32 @@ def main():
         # the mean) and a launch ends with its longest one running alone — ~130 ms whatever the batch.  Measured on 20M
         # rows: 1.32 / 1.44 / 1.62 G expansions/s at 1 / 2 / 4 resident rounds per launch; the marginal rate between
         # them is 1.86 G (profiles/r03)
+        # Round 4: the tables live per resident row, so what a batch costs beyond the rows' 40 GB is its scored lists
+        # (0.8 MB per traversal), and two objects take the batches in turn (94 GB each at 4 x 16384).
         from rad_amd._lib import RadHipError, E_NOMEM
         from rad_amd.device import DeviceTraversal
         cap = idx.traversal_capacity()
         for mult in (4.0, 3.0, 2.0, 1.5, 1.0):
             args.nq = int(cap * mult)
+            probes = []
             try:
-                probe = DeviceTraversal(idx, idx.read_vectors(0, args.nq), args.n_to_score)
-                probe.close()
+                q0 = idx.read_vectors(0, args.nq)
+                for _ in range(1 if args.no_overlap else 2):
+                    probes.append(DeviceTraversal(idx, q0, args.n_to_score, slots=True))
                 break
             except RadHipError as e:
                 if e.code != E_NOMEM or mult == 1.0:
                     raise
+            finally:
+                for p_ in probes:
+                    p_.close()
         args.nq = int(grp.allreduce([args.nq], "min")[0])       # the same batch size on every rank
     # replicas / single GPU: every rank runs its OWN query batches (the queries are what is split)
     batches = query_batches(idx, n_batches, args.nq, n, 4242 + rank)
-    leg = run_traversal_leg(args, idx, batches, args.steps, args.warmup, barrier)
+    leg = run_traversal_leg(args, idx, batches, args.steps, args.warmup, barrier, overlap=not args.no_overlap)
     recall = recall_of(idx, batches[-1][:128]) if (rank == 0 and args.graph == "built") else None
-    note(f"recall@10 of the built graph: {recall}")
+    recall400 = recall_of(idx, batches[-1][:128], ef=400) if (rank == 0 and args.graph == "built") else None
+    note(f"recall@10 of the built graph: {recall} at ef 128, {recall400} at ef 400")
 
     sums = grp.allreduce([leg["pops"], leg["evals"]], "sum")
     elapsed_max = float(grp.allreduce([leg["elapsed"]], "max")[0])
@@ -705,7 +928,11 @@ def main():
                     f"(level-0 width {2 * args.connectivity}), {args.nq} concurrent best-first RAD traversals per GPU to "
                     f"n_to_score={args.n_to_score}, synthetic {corpus_desc}, {graph_desc}",
         "rows": n, "ndim": args.ndim, "connectivity": args.connectivity, "nq_per_gpu": args.nq, "n_to_score": args.n_to_score,
-        "corpus_mode": args.corpus_mode, "graph_recall_at_10_ef128": recall,
+        "corpus_mode": args.corpus_mode, "expansion_add": args.expansion_add, "graph_build_s": t_build,
+        "graph_recall_at_10_ef128": recall, "graph_recall_at_10_ef400": recall400,
+        "traversal_state": {"objects": leg["objects"], "rows_with_tables_per_object": leg["slots"] or args.nq, "bytes": leg["state_bytes"],
+                            "what": "tables / key pool / run table per resident row of the kernel (RADHIP_TRAV_SLOTS), query + header + scored list per traversal; "
+                                    "two objects on two streams take the batches in turn (radhip_traversal_start / _finish)"},
         "layout": None if lay is None else {"seconds": lay.seconds, "groups_per_row": lay.groups_per_row, "degree": lay.degree},
         "parallelism": "single GPU",
     }
@@ -724,23 +951,69 @@ def main():
             # measured offline (rocprofv3 --pmc passes): only valid for the kernels it was measured on — the hash of the
             # traversal kernels' sources must match, or the figure is dropped, not printed
             if (pj.get("traverse_build_id") == _lib.traverse_build_id() and pj.get("n") == n and pj.get("nq") == args.nq and pj.get("n_to_score") == args.n_to_score
-                    and pj.get("corpus_mode", 1) == args.corpus_mode and pj.get("table") == leg["table"]):
+                    and pj.get("corpus_mode", 1) == args.corpus_mode and pj.get("table") == leg["table"] and pj.get("expansion_add", 64) == args.expansion_add):
+                rf = out["roofline"]
                 tr = pj.get("hbm_bytes_per_launch")
-                out["roofline"]["traffic"] = tr
-                out["roofline"]["traffic_source"] = "profiles/traffic_latest.json (rocprofv3 --pmc, separate passes, measured offline)"
+                rf["traffic"] = tr
+                rf["traffic_source"] = "profiles/traffic_latest.json (rocprofv3 --pmc, separate passes, measured offline; every memory-side read request is a 128-B line, partial writes are 32-B requests: profiles/r04/probe_request_size.md)"
+                busy_per_launch = rf["kernel_busy_ms_per_launch"] * 1e-3
                 if tr:
-                    out["roofline"]["hbm_real_gbs"] = tr / (out["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
-                # the second ceiling of a pointer-chasing kernel: memory-side REQUESTS per second.  An MI355X serves 38 G
-                # independent random 128-B line reads per second over footprints >= 16 GiB however many wavefronts ask
-                # (scripts/latency_footprint.hip, profiles/r03/latency_footprint.log); partial-line writes cost more.
+                    rf["hbm_real_gbs"] = tr / busy_per_launch / 1e9
+                # The ceiling this kernel really sits under: memory-side REQUESTS.  scripts/probe_request_size.hip (profiles/r04):
+                # an MI355X serves 38-49 G random 128-B line reads per second over a 32 GiB footprint (38 when a 16-B-per-lane
+                # load touches 64 lines, 49 when it touches 32 or fewer), 49 G full 64-B writes per second, but only 21.9 G
+                # writes of 32 B or less per second — a table entry store costs 2.2 line reads.
                 rq, wq = pj.get("read_requests_128B"), (pj.get("write_requests") or {}).get("total")
+                w64 = (pj.get("write_requests") or {}).get("64B") or 0
                 if rq and wq:
-                    rate = (rq + wq) / (out["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
-                    out["roofline"]["memory_requests"] = {
-                        "reads_per_launch": rq, "writes_per_launch": wq, "achieved_G_per_s": rate,
+                    rate = (rq + wq) / busy_per_launch / 1e9
+                    rf["memory_requests"] = {
+                        "reads_per_launch": rq, "writes_per_launch": wq, "writes_64B_per_launch": w64, "achieved_G_per_s": rate,
                         "device_random_line_reads_G_per_s": RANDOM_LINE_PEAK_G, "frac": rate / RANDOM_LINE_PEAK_G}
+                    # what the SAME request mix could reach if nothing but the memory system's request rates bound it
+                    t_model = rq / (READ_LINES_G * 1e9) + (wq - w64) / (PARTIAL_WRITES_G * 1e9) + w64 / (FULL_WRITES_G * 1e9)
+                    alg = rf["algorithmic_bytes_per_launch"]
+                    rf["attainable"] = {
+                        "by_request_count_GBs": alg / ((rq + wq) / (RANDOM_LINE_PEAK_G * 1e9)) / 1e9,
+                        "by_request_cost_model_GBs": alg / t_model / 1e9,
+                        "model": f"time >= reads / {READ_LINES_G} G/s + writes(<= 32 B) / {PARTIAL_WRITES_G} G/s + writes(64 B) / {FULL_WRITES_G} G/s "
+                                 "(rates measured by scripts/probe_request_size.hip on this device class, 32 GiB footprint)",
+                        "achieved_over_model": rf["achieved"] / (alg / t_model / 1e9)}
         except Exception:
             pass
+
+    if world > 1 and not args.no_peer_leg:
+        # side leg 1: the peer-mapped corpus (rows sharded, single-GPU kernel over xGMI reads); this rank's whole-corpus index is
+        # still here and serves as the parity reference
+        pbox = {}
+
+        def _pleg():
+            try:
+                pbox["res"] = run_peer_leg(args, idx, grp, rank, world, local_rank, barrier)
+            except BaseException as e:   # noqa: BLE001 - reported in the line, never silent
+                pbox["err"] = f"{type(e).__name__}: {e}"
+        th = threading.Thread(target=_pleg, daemon=True)
+        th.start()
+        th.join(args.sharded_timeout)
+        if th.is_alive():
+            # a rank is stuck inside the leg (a peer that died in the descriptor exchange): the replicas leg is measured, print and leave
+            if rank == 0:
+                config["parallelism"] = "replicas (--mode replicas): every GPU holds the whole corpus and graph, the query batch is split, no collective"
+                out["peer_mapped"] = {"error": f"no result after {args.sharded_timeout:.0f} s"}
+                out["replicas"] = {"value": value_replicas, "unit": "expansions/s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0 if args.mode == "replicas" else 4)
+        errs = [e for e in grp.allgather_obj(pbox.get("err", "")) if e]
+        if errs:
+            out["peer_mapped"] = {"error": "; ".join(sorted(set(errs)))[:400]}
+            if args.mode == "peer":
+                raise SystemExit(f"bench.py: the peer-mapped leg failed ({out['peer_mapped']['error']}) and --mode peer asked for its value")
+        else:
+            peer, pp_ok, pp_n = peer_report(args, grp, pbox["res"], world, B)
+            if pp_ok != pp_n:
+                raise SystemExit(f"bench.py: traversals over the peer-mapped corpus differ from the whole-corpus index ({peer['parity_vs_whole_corpus_index']}): no value printed")
+            out["peer_mapped"] = peer
+            note(f"peer-mapped leg: {peer['value'] / 1e9:.3f} G expansions/s over {world} GPUs")
 
     if world > 1:
         box = {}
@@ -779,6 +1052,11 @@ def main():
             config["nq_per_gpu"] = args.sharded_nq
             out["roofline"]["note"] = ("roofline of the single-GPU traversal kernel on this rank (replicas leg); the sharded step is "
                                        "bound by its two collectives per frontier step, not by HBM")
+        elif args.mode == "peer" and "value" in out.get("peer_mapped", {}):
+            pm = out["peer_mapped"]
+            out["value"], out["ms_per_step"], out["evals_per_s"] = pm["value"], pm["ms_per_step"], pm["evals_per_s"]
+            out["steps"] = pm["steps"]
+            config["parallelism"] = "peer-mapped (--mode peer): " + pm["partitioning"]
         else:
             config["parallelism"] = "replicas (--mode replicas): " + replicas["partitioning"]
         out["sharded"], out["replicas"] = sharded, replicas
@@ -808,21 +1086,39 @@ def main():
                                          "list (slots, and, or); traversals taken alternately from the head and the tail of the last batch")
             if not ok:
                 raise SystemExit(f"bench.py: GPU and oracle disagree on the parity sample ({sample}): no value printed")
-        if args.corpus_mode != 1 and not args.no_reference_corpus and args.graph == "built":
-            # round 1's corpus on the same kernel, for continuity (its built graph is not a usable HNSW graph at this
-            # size: recall is reported beside the numbers)
-            idx.close()
-            idx1, tb1, _ = build_index(args, 1, local_rank, layout=False)
-            b1 = query_batches(idx1, 1 + min(args.steps, 3), args.nq, n, 4242)
-            leg1 = run_traversal_leg(args, idx1, b1, min(args.steps, 3), 1, lambda: None)
-            rf1 = roofline_of(leg1, B)
-            out["reference_corpus_r01"] = {
-                "value": leg1["pops"] / leg1["elapsed"], "unit": "expansions/s", "evals_per_s": leg1["evals"] / leg1["elapsed"],
-                "evals_per_expansion": leg1["evals"] / max(leg1["pops"], 1), "roofline_frac": rf1["frac"],
-                "roofline_achieved_gbs": rf1["achieved"], "avg_launch_ms": rf1["avg_launch_ms"], "table": leg1["table"],
-                "graph_recall_at_10_ef128": recall_of(idx1, b1[-1][:128]), "build_s": tb1, "steps": min(args.steps, 3),
-                "workload": "round 1's bench workload: two-level clustered sparse corpus, HNSW graph built on the GPU"}
-            idx1.close()
+        if not args.no_kernel_legs:
+            try:
+                out["kernels"] = kernel_legs(idx, n, B)
+                note(f"kernel legs: {out['kernels']}")
+            except Exception as e:   # noqa: BLE001 - a side leg must not cost the line
+                out["kernels"] = {"error": f"{type(e).__name__}: {e}"}
+        idx.close()
+        if args.secondary_expansion_add and args.secondary_expansion_add != args.expansion_add and args.graph == "built":
+            # the graph rounds 1-3 benched (expansion_add 64: a lighter build, more new nodes per expansion), on the same kernel
+            try:
+                a2 = argparse.Namespace(**vars(args)); a2.expansion_add = args.secondary_expansion_add
+                idx2, tb2, _ = build_index(a2, args.corpus_mode, local_rank, layout=(args.table == "group"))
+                st2 = min(args.steps, 4)
+                b2 = query_batches(idx2, 1 + st2, args.nq, n, 4242)
+                leg2 = run_traversal_leg(a2, idx2, b2, st2, 1, lambda: None, overlap=not args.no_overlap)
+                rf2 = roofline_of(leg2, B)
+                out["secondary_graph"] = {
+                    "value": leg2["pops"] / leg2["elapsed"], "unit": "expansions/s", "ms_per_step": leg2["elapsed"] / st2 * 1e3, "steps": st2, "warmup": 1,
+                    "evals_per_s": leg2["evals"] / leg2["elapsed"], "evals_per_expansion": leg2["evals"] / max(leg2["pops"], 1),
+                    "roofline_frac": rf2["frac"], "roofline_achieved_gbs": rf2["achieved"], "avg_launch_ms": rf2["avg_launch_ms"],
+                    "kernel_busy_ms_per_launch": rf2["kernel_busy_ms_per_launch"], "table": leg2["table"],
+                    "expansion_add": a2.expansion_add, "graph_build_s": tb2,
+                    "graph_recall_at_10_ef128": recall_of(idx2, b2[-1][:128]), "graph_recall_at_10_ef400": recall_of(idx2, b2[-1][:128], ef=400),
+                    "workload": f"the bench workload of rounds 1-3: the same corpus and kernel, the graph built with expansion_add={a2.expansion_add}"}
+                idx2.close()
+                note(f"secondary graph (expansion_add {a2.expansion_add}): {out['secondary_graph']['value'] / 1e9:.3f} G expansions/s")
+            except Exception as e:   # noqa: BLE001
+                out["secondary_graph"] = {"error": f"{type(e).__name__}: {e}"}
+        if not args.no_config_legs:
+            try:
+                out["configs"] = config_legs(args, local_rank)
+            except Exception as e:   # noqa: BLE001
+                out["configs"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out), flush=True)
     grp.barrier()
     grp.close()

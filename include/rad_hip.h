@@ -283,6 +283,9 @@ int radhip_traversal_start(radhip_traversal_t *t);
 int radhip_traversal_finish(radhip_traversal_t *t, uint32_t *out_running);
 /* milliseconds on the device's clock from the start of `from`'s last launch to the end of `to`'s last launch */
 int radhip_traversal_elapsed_between(const radhip_traversal_t *from, const radhip_traversal_t *to, double *out_ms);
+/* start and end of the object's last finished launch, in ms on the device's clock since a fixed point of the process:
+ * the device's busy time over overlapping launches of several objects is the union of these intervals */
+int radhip_traversal_launch_interval(const radhip_traversal_t *t, double *out_start_ms, double *out_end_ms);
 /* resident rows whose state the batch shares (RADHIP_TRAV_SLOTS); 0 = state per traversal */
 uint32_t radhip_traversal_slots(const radhip_traversal_t *t);
 int radhip_traversal_stats(const radhip_traversal_t *t, radhip_trav_stats_t *out /* [nq] */);
@@ -340,6 +343,23 @@ int radhip_traversal_frontier(const radhip_traversal_t *t, uint64_t *out_keys, u
  * (radhip_index_*_shard).  When the device has no room for the shard beside the corpus the shard leaves through
  * host memory and the corpus is freed first. */
 int radhip_index_keep_rows(radhip_index_t *idx, uint64_t first, uint64_t count);
+/* ---- peer-mapped corpus (round 4): BASELINE's row partitioning without a lock step ---------------------------------
+ * Every rank of a node maps the row shards of ALL ranks into one contiguous virtual address range (HIP virtual memory
+ * management; the peers' shards are their exported dmabuf descriptors, read over xGMI), seals it, and from then on holds
+ * the whole corpus as far as every kernel is concerned: radhip_traversal_* run unchanged, a gather of a remote row is a
+ * 128-B read over the fabric.  No collective, results bit-identical to one GPU by construction.  Replaces nothing in the
+ * reference (its corpus lives in one usearch index in one process: README.md:45-58); it is how a corpus that does not fit
+ * one GPU is served at the single-GPU kernel's rate instead of the lock-step loop's.
+ *   peer_create -> peer_fill_synth | peer_fill_rows -> peer_export (one fd, handed to every peer) -> peer_import (each
+ *   peer's fd) -> peer_seal.   Rows per shard = ceil(n_total / world) rounded up to the allocation granule (2 MiB). */
+int radhip_index_peer_create(radhip_index_t *idx, int rank, int world, uint64_t n_total, uint64_t *out_rows_per_shard);
+int radhip_index_peer_fill_synth(radhip_index_t *idx, uint64_t seed, int mode);
+int radhip_index_peer_fill_rows(radhip_index_t *idx, const uint8_t *rows, uint64_t count);
+int radhip_index_peer_export(radhip_index_t *idx, int *out_fd);
+int radhip_index_peer_import(radhip_index_t *idx, int peer_rank, int fd);
+int radhip_index_peer_seal(radhip_index_t *idx);
+/* the graph of `src` copied device to device into `dst` (same device, same process, same row widths) */
+int radhip_index_copy_graph_from(radhip_index_t *dst, radhip_index_t *src);
 typedef struct radhip_shard radhip_shard_t;
 typedef struct radhip_comm radhip_comm_t;
 /* queries_all: world * nq query rows, rank-major — traversal (r, q) belongs to rank r; every rank passes

@@ -103,11 +103,19 @@ SIGNATURES = {
     "radhip_traversal_create": (C.c_int, [_P, _P, _U32, _U64, _U32, C.POINTER(_P)]),
     "radhip_traversal_destroy": (C.c_int, [_P]),
     "radhip_traversal_reset": (C.c_int, [_P, _P]),
+    "radhip_index_peer_create": (C.c_int, [_P, C.c_int, C.c_int, _U64, C.POINTER(_U64)]),
+    "radhip_index_peer_fill_synth": (C.c_int, [_P, _U64, C.c_int]),
+    "radhip_index_peer_fill_rows": (C.c_int, [_P, _P, _U64]),
+    "radhip_index_peer_export": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "radhip_index_peer_import": (C.c_int, [_P, C.c_int, C.c_int]),
+    "radhip_index_peer_seal": (C.c_int, [_P]),
+    "radhip_index_copy_graph_from": (C.c_int, [_P, _P]),
     "radhip_traversal_run": (C.c_int, [_P, _U64, C.POINTER(_U32)]),
     "radhip_traversal_start": (C.c_int, [_P]),
     "radhip_traversal_finish": (C.c_int, [_P, C.POINTER(_U32)]),
     "radhip_traversal_elapsed_between": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     "radhip_traversal_slots": (_U32, [_P]),
+    "radhip_traversal_launch_interval": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "radhip_traversal_stats": (C.c_int, [_P, _P]),
     "radhip_traversal_results": (C.c_int, [_P, _U32, _P, _P, _P, _U64, C.POINTER(_U64)]),
     "radhip_traversal_pop_log": (C.c_int, [_P, _U32, _P, _P, _U64, C.POINTER(_U64)]),

@@ -39,6 +39,7 @@ void radhip_set_error(const char *fmt, ...);
     } while (0)
 
 // ------------------------------------------------------------- the index --
+struct RhPeerMap;
 struct radhip_index {
     uint32_t ndim_bits = 0, row_bytes = 0, row_stride = 0, lpr = 0;  // lpr = 16-B lanes per row
     uint32_t M = 0, cap0 = 0, ef_add = 0;
@@ -76,6 +77,9 @@ struct radhip_index {
     uint32_t n_top = 0;
     bool d_graph_valid = false;
     uint64_t fp_cap_rows = 0;
+    // peer-mapped corpus (index.hip, round 4): d_fp points into a reserved virtual range that holds the row shards of all
+    // ranks of a node, this rank's own allocation and the peers' imported ones (xGMI).  Such a corpus is read-only.
+    struct RhPeerMap *peer = nullptr;
     uint64_t cap_nodes = 0, cap_upper = 0;   // allocated rows of d_levels / d_adj0 / d_upper_row and of d_adjU (add() grows them by half)
     uint64_t device_bytes = 0;
     // bumped by every call that changes the graph or the corpus (load_graph, synth_graph, add,

@@ -67,12 +67,15 @@ extern "C" int radhip_index_create(uint32_t ndim_bits, uint32_t connectivity,
 }
 
 void rh_layout_free(radhip_index *idx);   // layout.hip
+static void rh_peer_release(radhip_index *idx);
+#define RH_REQUIRE_OWN_CORPUS(idx) do { if ((idx)->peer) RH_FAIL(RADHIP_E_STATE, "the corpus of this index is peer-mapped (radhip_index_peer_*): it is read-only"); } while (0)
 
 static void free_dev(radhip_index *idx) {
     if (!idx->dev_ready) return;
     (void)hipSetDevice(idx->device);
     rh_layout_free(idx);
-    if (idx->d_fp) (void)hipFree(idx->d_fp);
+    if (idx->peer) rh_peer_release(idx);
+    else if (idx->d_fp) (void)hipFree(idx->d_fp);
     if (idx->d_levels) (void)hipFree(idx->d_levels);
     if (idx->d_adj0) (void)hipFree(idx->d_adj0);
     if (idx->d_upper_row) (void)hipFree(idx->d_upper_row);
@@ -211,6 +214,7 @@ static int load_vectors_impl(radhip_index *idx, const uint8_t *rows, uint64_t n,
     if (!idx || (!rows && n)) RH_FAIL(RADHIP_E_INVALID, "null argument");
     if (shard && (n == 0 || first + n > n_total)) RH_FAIL(RADHIP_E_INVALID, "rows [first, first+count) must be a non-empty range of n_total");
     std::lock_guard<std::mutex> lk(idx->mu);
+    RH_REQUIRE_OWN_CORPUS(idx);
     try {
         idx->h_rows.assign((size_t)n * idx->row_stride, 0);
     } catch (...) {
@@ -328,6 +332,7 @@ static int synth_vectors_impl(radhip_index *idx, uint64_t n, uint64_t first_row,
     if (first_row + n > n_total) RH_FAIL(RADHIP_E_INVALID, "rows [first, first+n) exceed n_total");
     if (shard && n == 0) RH_FAIL(RADHIP_E_INVALID, "a shard holds at least one row");
     std::lock_guard<std::mutex> lk(idx->mu);
+    RH_REQUIRE_OWN_CORPUS(idx);
     idx->h_rows_pending = false;
     std::vector<uint8_t>().swap(idx->h_rows);
     RH_TRY(rh_ensure_device(idx));
@@ -362,6 +367,7 @@ extern "C" int radhip_index_keep_rows(radhip_index_t *idx, uint64_t first, uint6
     if (!idx) RH_FAIL(RADHIP_E_INVALID, "null index");
     std::lock_guard<std::mutex> lk(idx->mu);
     if (!idx->has_vectors) RH_FAIL(RADHIP_E_STATE, "no vectors loaded");
+    RH_REQUIRE_OWN_CORPUS(idx);
     RH_REQUIRE_FULL_CORPUS(idx);
     if (count == 0 || first + count > idx->n) RH_FAIL(RADHIP_E_RANGE, "rows [%llu, %llu) out of range (%llu rows)",
                                                       (unsigned long long)first, (unsigned long long)(first + count),
@@ -933,4 +939,214 @@ extern "C" int radhip_tanimoto_gather(radhip_index_t *idx, const uint8_t *querie
     cleanup();
     return RADHIP_OK;
 #undef RH_G
+}
+
+// ================================================================== peer-mapped corpus (round 4)
+// BASELINE's partitioning — the fingerprint rows of one corpus sharded by contiguous slot range over the GPUs of a node —
+// WITHOUT a lock step: every rank maps the row shards of all ranks into ONE contiguous virtual address range (HIP virtual
+// memory management: its own physical allocation plus the peers' allocations imported through dmabuf file descriptors,
+// reached over xGMI), so that `fp[slot]` is valid for every slot of the corpus and the single-GPU traversal kernel runs
+// UNCHANGED: a gather of a remote row is a 128-B read over the fabric, one more hop of latency in a kernel that already
+// keeps thousands of gathers in flight.  No collective, no frontier step, results bit-identical by construction (the same
+// kernel reads the same bytes).  Per rank: N / G rows of HBM instead of N; per expansion ~4 x 128 B x (G - 1) / G cross the
+// fabric.  The row-sharded lock-step loop (shard.hip: RCCL all-gather of the frontier candidates) stays, as north_star's
+// stated exchange; this is the mode for throughput.
+//   radhip_index_peer_create -> _peer_fill_synth | _peer_fill_rows -> _peer_export (fd to every peer) ->
+//   _peer_import (every peer's fd) -> _peer_seal
+struct RhPeerMap {
+    int rank = 0, world = 0;
+    uint64_t n_total = 0, rows_per_shard = 0;
+    size_t shard_bytes = 0, va_bytes = 0;
+    uint8_t *va = nullptr;
+    std::vector<hipMemGenericAllocationHandle_t> handles;   // [world]
+    std::vector<uint8_t> have, mapped;                      // [world]
+    bool sealed = false;
+};
+
+static void rh_peer_release(radhip_index *idx) {
+    RhPeerMap *pm = idx->peer;
+    if (!pm) return;
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < pm->world; ++r) {
+        if (pm->mapped[r]) (void)hipMemUnmap(pm->va + (size_t)r * pm->shard_bytes, pm->shard_bytes);
+        if (pm->have[r]) (void)hipMemRelease(pm->handles[r]);
+    }
+    if (pm->va) (void)hipMemAddressFree(pm->va, pm->va_bytes);
+    idx->device_bytes -= std::min<uint64_t>(idx->device_bytes, pm->shard_bytes);
+    delete pm;
+    idx->peer = nullptr; idx->d_fp = nullptr; idx->fp_cap_rows = 0;
+}
+
+static int peer_map_one(radhip_index *idx, int r) {
+    RhPeerMap *pm = idx->peer;
+    uint8_t *at = pm->va + (size_t)r * pm->shard_bytes;
+    RH_HIP(hipMemMap(at, pm->shard_bytes, 0, pm->handles[r], 0));
+    pm->mapped[r] = 1;
+    hipMemAccessDesc d = {};
+    d.location.type = hipMemLocationTypeDevice;
+    d.location.id = idx->device;
+    d.flags = hipMemAccessFlagsProtReadWrite;
+    RH_HIP(hipMemSetAccess(at, pm->shard_bytes, &d, 1));
+    return RADHIP_OK;
+}
+
+// Reserve the range for all n_total rows, create and map this rank's shard.  Rows per shard = ceil(n_total / world) rounded up
+// to the allocation granularity (2 MiB = 16384 rows of 128 B), so that slot i sits at va + i * row_stride on every rank.
+// Until radhip_index_peer_seal the index is a SHARD (rows [rank * rows_per_shard, ...) resident): the row-sharded loop can
+// use it as it is.
+extern "C" int radhip_index_peer_create(radhip_index_t *idx, int rank, int world, uint64_t n_total, uint64_t *out_rows_per_shard) {
+    if (!idx) RH_FAIL(RADHIP_E_INVALID, "null index");
+    if (world < 1 || rank < 0 || rank >= world || n_total == 0) RH_FAIL(RADHIP_E_INVALID, "bad rank / world / n_total");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RH_REQUIRE_OWN_CORPUS(idx);
+    if (idx->has_vectors || idx->d_fp || idx->h_rows_pending) RH_FAIL(RADHIP_E_STATE, "the index holds a corpus already");
+    RH_TRY(rh_ensure_device(idx));
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = idx->device;
+    prop.requestedHandleType = hipMemHandleTypePosixFileDescriptor;
+    size_t gran = 0;
+    RH_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    // (the API's granule is 4 KiB on this stack; shards start on 2-MiB boundaries so that every shard can be backed and
+    // translated in the large fragments a 2-MiB-aligned range allows)
+    if (gran < ((size_t)2 << 20) && ((size_t)2 << 20) % (gran ? gran : 1) == 0) gran = (size_t)2 << 20;
+    if (gran == 0 || gran % idx->row_stride) RH_FAIL(RADHIP_E_HIP, "allocation granularity %zu is not a multiple of the row stride", gran);
+    const uint64_t rows_gran = gran / idx->row_stride;
+    uint64_t rps = (n_total + (uint64_t)world - 1) / (uint64_t)world;
+    rps = (rps + rows_gran - 1) / rows_gran * rows_gran;
+    RhPeerMap *pm = new (std::nothrow) RhPeerMap();
+    if (!pm) RH_FAIL(RADHIP_E_NOMEM, "out of host memory");
+    pm->rank = rank; pm->world = world; pm->n_total = n_total; pm->rows_per_shard = rps;
+    pm->shard_bytes = (size_t)rps * idx->row_stride;
+    pm->va_bytes = pm->shard_bytes * (size_t)world;
+    pm->handles.resize(world); pm->have.assign(world, 0); pm->mapped.assign(world, 0);
+    idx->peer = pm;
+    void *va = nullptr;
+    hipError_t e = hipMemAddressReserve(&va, pm->va_bytes, gran, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGetLastError(); delete pm; idx->peer = nullptr; RH_FAIL(RADHIP_E_HIP, "hipMemAddressReserve(%zu) failed: %s", pm->va_bytes, hipGetErrorString(e)); }
+    pm->va = (uint8_t *)va;
+    e = hipMemCreate(&pm->handles[rank], pm->shard_bytes, &prop, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        const size_t sb = pm->shard_bytes;
+        rh_peer_release(idx);
+        RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP, "hipMemCreate(%zu) for this rank's shard failed: %s", sb, hipGetErrorString(e));
+    }
+    pm->have[rank] = 1;
+    idx->device_bytes += pm->shard_bytes;
+    { const int rc = peer_map_one(idx, rank); if (rc != RADHIP_OK) { rh_peer_release(idx); return rc; } }
+    const uint64_t first = (uint64_t)rank * rps;
+    idx->d_fp = (uint4 *)(pm->va + (size_t)rank * pm->shard_bytes);
+    idx->fp_cap_rows = rps;
+    idx->n = first < n_total ? std::min<uint64_t>(rps, n_total - first) : 0;
+    idx->sharded = true; idx->shard_first = first; idx->n_total = n_total;
+    if (out_rows_per_shard) *out_rows_per_shard = rps;
+    return RADHIP_OK;
+}
+
+// this rank's rows of the closed-form corpus (the generator of radhip_index_synth_vectors), written into its shard
+extern "C" int radhip_index_peer_fill_synth(radhip_index_t *idx, uint64_t seed, int mode) {
+    if (!idx) RH_FAIL(RADHIP_E_INVALID, "null index");
+    if (mode < 0 || mode > 2) RH_FAIL(RADHIP_E_INVALID, "mode must be 0, 1 or 2");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (!idx->peer || idx->peer->sealed) RH_FAIL(RADHIP_E_STATE, "radhip_index_peer_create first (and fill before sealing)");
+    RH_HIP(hipSetDevice(idx->device));
+    if (idx->n) {
+        hipLaunchKernelGGL(synth_rows_kernel, dim3(256 * 16), dim3(256), 0, idx->stream, (uint64_t *)idx->d_fp, idx->n,
+                           idx->row_stride / 8, idx->row_bytes, idx->ndim_bits, idx->shard_first, idx->n_total, seed, mode);
+        RH_HIP(hipGetLastError());
+        RH_HIP(hipStreamSynchronize(idx->stream));
+    }
+    idx->has_vectors = true;
+    idx->graph_gen++;
+    return RADHIP_OK;
+}
+// ... or from the host: `rows` = this rank's rows [rank * rows_per_shard, ...) of the corpus, row_bytes each
+extern "C" int radhip_index_peer_fill_rows(radhip_index_t *idx, const uint8_t *rows, uint64_t count) {
+    if (!idx || (!rows && count)) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (!idx->peer || idx->peer->sealed) RH_FAIL(RADHIP_E_STATE, "radhip_index_peer_create first (and fill before sealing)");
+    if (count != idx->n) RH_FAIL(RADHIP_E_INVALID, "this rank's shard holds %llu rows (got %llu)", (unsigned long long)idx->n, (unsigned long long)count);
+    RH_HIP(hipSetDevice(idx->device));
+    const uint64_t step = 1u << 20;
+    std::vector<uint8_t> stage;
+    try { stage.assign((size_t)std::min<uint64_t>(step, std::max<uint64_t>(count, 1)) * idx->row_stride, 0); } catch (...) { RH_FAIL(RADHIP_E_NOMEM, "out of host memory"); }
+    for (uint64_t f = 0; f < count; f += step) {
+        const uint64_t c = std::min(step, count - f);
+        for (uint64_t i = 0; i < c; ++i) memcpy(stage.data() + i * idx->row_stride, rows + (f + i) * idx->row_bytes, idx->row_bytes);
+        RH_HIP(hipMemcpy((uint8_t *)idx->d_fp + f * idx->row_stride, stage.data(), (size_t)c * idx->row_stride, hipMemcpyHostToDevice));
+    }
+    idx->has_vectors = true;
+    idx->graph_gen++;
+    return RADHIP_OK;
+}
+// a file descriptor (dmabuf) of this rank's shard for the peers: the caller passes it on (SCM_RIGHTS over a Unix socket between
+// processes, as it is inside one process) and closes it
+extern "C" int radhip_index_peer_export(radhip_index_t *idx, int *out_fd) {
+    if (!idx || !out_fd) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (!idx->peer) RH_FAIL(RADHIP_E_STATE, "radhip_index_peer_create first");
+    RH_HIP(hipSetDevice(idx->device));
+    int fd = -1;
+    RH_HIP(hipMemExportToShareableHandle(&fd, idx->peer->handles[idx->peer->rank], hipMemHandleTypePosixFileDescriptor, 0));
+    *out_fd = fd;
+    return RADHIP_OK;
+}
+// map the shard of rank `peer_rank` (its exported descriptor) at its place in this rank's range
+extern "C" int radhip_index_peer_import(radhip_index_t *idx, int peer_rank, int fd) {
+    if (!idx) RH_FAIL(RADHIP_E_INVALID, "null index");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RhPeerMap *pm = idx->peer;
+    if (!pm || pm->sealed) RH_FAIL(RADHIP_E_STATE, "radhip_index_peer_create first (and import before sealing)");
+    if (peer_rank < 0 || peer_rank >= pm->world || peer_rank == pm->rank) RH_FAIL(RADHIP_E_INVALID, "peer rank %d out of range", peer_rank);
+    if (pm->have[peer_rank]) RH_FAIL(RADHIP_E_STATE, "the shard of rank %d is mapped already", peer_rank);
+    RH_HIP(hipSetDevice(idx->device));
+    RH_HIP(hipMemImportFromShareableHandle(&pm->handles[peer_rank], (void *)(uintptr_t)fd, hipMemHandleTypePosixFileDescriptor));
+    pm->have[peer_rank] = 1;
+    return peer_map_one(idx, peer_rank);
+}
+// every shard is mapped: the index holds the WHOLE corpus from here on (slot i at d_fp + i * lpr), read-only
+extern "C" int radhip_index_peer_seal(radhip_index_t *idx) {
+    if (!idx) RH_FAIL(RADHIP_E_INVALID, "null index");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    RhPeerMap *pm = idx->peer;
+    if (!pm) RH_FAIL(RADHIP_E_STATE, "radhip_index_peer_create first");
+    if (!idx->has_vectors) RH_FAIL(RADHIP_E_STATE, "fill this rank's shard first");
+    for (int r = 0; r < pm->world; ++r) if (!pm->mapped[r]) RH_FAIL(RADHIP_E_STATE, "the shard of rank %d is not mapped yet", r);
+    RH_HIP(hipSetDevice(idx->device));
+    RH_HIP(hipDeviceSynchronize());
+    pm->sealed = true;
+    idx->d_fp = (uint4 *)pm->va;
+    idx->n = pm->n_total; idx->fp_cap_rows = pm->rows_per_shard * (uint64_t)pm->world;
+    idx->sharded = false; idx->shard_first = 0; idx->n_total = 0;
+    idx->graph_gen++;
+    return RADHIP_OK;
+}
+// the graph of `src` (same device, same process) copied device to device into `dst` (a peer-mapped index adopts the graph of
+// the index that built it without a trip through host memory)
+extern "C" int radhip_index_copy_graph_from(radhip_index_t *dst, radhip_index_t *src) {
+    if (!dst || !src || dst == src) RH_FAIL(RADHIP_E_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lk(dst < src ? dst->mu : src->mu);
+    std::lock_guard<std::mutex> lk2(dst < src ? src->mu : dst->mu);
+    RH_TRY(rh_ensure_device(src));
+    RH_TRY(rh_ensure_device(dst));
+    if (!src->has_graph || !src->d_graph_valid) RH_FAIL(RADHIP_E_STATE, "the source has no graph on its device");
+    if (src->device != dst->device || src->cap0 != dst->cap0 || src->M != dst->M) RH_FAIL(RADHIP_E_INVALID, "source and destination differ in device or row widths");
+    rh_layout_invalidate(dst);
+    dst->g_n = src->g_n; dst->max_level = src->max_level; dst->entry = src->entry; dst->n_upper_rows = src->n_upper_rows;
+    dst->has_graph = false; dst->d_graph_valid = false;
+    RH_TRY(rh_alloc_graph_dev(dst));
+    RH_HIP(hipMemcpy(dst->d_levels, src->d_levels, src->g_n, hipMemcpyDeviceToDevice));
+    RH_HIP(hipMemcpy(dst->d_adj0, src->d_adj0, src->g_n * src->cap0 * 4, hipMemcpyDeviceToDevice));
+    RH_HIP(hipMemcpy(dst->d_upper_row, src->d_upper_row, src->g_n * 4, hipMemcpyDeviceToDevice));
+    if (src->n_upper_rows) RH_HIP(hipMemcpy(dst->d_adjU, src->d_adjU, src->n_upper_rows * src->M * 4, hipMemcpyDeviceToDevice));
+    dst->h_top = src->h_top;
+    if (dst->h_top.empty() && src->n_top) { dst->h_top.resize(src->n_top); RH_HIP(hipMemcpy(dst->h_top.data(), src->d_top, (size_t)src->n_top * 4, hipMemcpyDeviceToHost)); }
+    RH_TRY(rh_upload_top(dst));
+    std::vector<int8_t>().swap(dst->h_levels); std::vector<uint32_t>().swap(dst->h_adj0);
+    std::vector<uint32_t>().swap(dst->h_upper_row); std::vector<uint32_t>().swap(dst->h_adjU);
+    dst->h_graph_valid = false; dst->d_graph_valid = true; dst->has_graph = true;
+    dst->graph_gen++;
+    return RADHIP_OK;
 }

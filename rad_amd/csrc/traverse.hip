@@ -611,6 +611,7 @@ extern "C" int radhip_traversal_destroy(radhip_traversal_t *t) {
     return RADHIP_OK;
 }
 
+static int trav_base_event(radhip_index *idx, hipEvent_t *out);
 static bool trav4_shape_ok(const radhip_index *idx);
 static int trav_forced_kernel();
 static int trav_capacity_of(radhip_index *idx, bool use4, uint32_t *out);
@@ -793,6 +794,7 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
     if (rc == 0 && hipEventCreate(&t->ev1) != hipSuccess) rc = RADHIP_E_HIP;
     if (rc != 0) { radhip_traversal_destroy(t); return rc; }
     P.queries = t->d_queries;
+    { hipEvent_t base_; (void)trav_base_event(idx, &base_); }
     rc = trav_upload_queries(t, queries);
     if (rc != 0) { radhip_traversal_destroy(t); return rc; }
     *out = t;
@@ -1108,6 +1110,37 @@ extern "C" int radhip_traversal_elapsed_between(const radhip_traversal_t *from, 
     float ms = 0.f;
     RH_HIP(hipEventElapsedTime(&ms, from->ev0, to->ev1));
     *out_ms = ms;
+    return RADHIP_OK;
+}
+// Start and end of the object's last (finished) launch in milliseconds on the device's clock since a fixed point of the
+// process (an event recorded once per device): launches of different objects overlap (start / finish on two streams), so
+// the time the device was busy is the union of their intervals, which the caller forms from these.
+static std::mutex g_base_mu;
+static hipEvent_t g_base_ev[64] = {nullptr};
+static int trav_base_event(radhip_index *idx, hipEvent_t *out) {
+    std::lock_guard<std::mutex> lk(g_base_mu);
+    const int d = idx->device;
+    if (d < 0 || d >= 64) RH_FAIL(RADHIP_E_INVALID, "device %d out of range", d);
+    if (!g_base_ev[d]) {
+        hipEvent_t e;
+        RH_HIP(hipEventCreate(&e));
+        if (hipEventRecord(e, idx->stream) != hipSuccess || hipEventSynchronize(e) != hipSuccess) { (void)hipEventDestroy(e); (void)hipGetLastError(); RH_FAIL(RADHIP_E_HIP, "recording the base event failed"); }
+        g_base_ev[d] = e;
+    }
+    *out = g_base_ev[d];
+    return RADHIP_OK;
+}
+extern "C" int radhip_traversal_launch_interval(const radhip_traversal_t *t, double *out_start_ms, double *out_end_ms) {
+    if (!t || !out_start_ms || !out_end_ms) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (t->in_flight) RH_FAIL(RADHIP_E_STATE, "a launch is still in flight");
+    if (t->launches == 0) RH_FAIL(RADHIP_E_STATE, "no launch yet");
+    RH_HIP(hipSetDevice(t->idx->device));
+    hipEvent_t base = nullptr;
+    RH_TRY(trav_base_event(t->idx, &base));
+    float a = 0.f, b = 0.f;
+    RH_HIP(hipEventElapsedTime(&a, base, t->ev0));
+    RH_HIP(hipEventElapsedTime(&b, base, t->ev1));
+    *out_start_ms = a; *out_end_ms = b;
     return RADHIP_OK;
 }
 // rows whose state the batch shares (0 = state per traversal)

@@ -150,6 +150,38 @@ class DeviceIndex:
         """Row-sharded multi-GPU mode: keep rows [first, first+count) of the corpus, free the rest."""
         check(self._L.radhip_index_keep_rows(self._h, first, count))
 
+    # -- peer-mapped corpus: the row shards of all ranks of a node in ONE virtual range (xGMI reads, no lock step) --------
+    def peer_create(self, rank: int, world: int, n_total: int) -> int:
+        """Reserve the range for n_total rows and create this rank's shard; returns the rows per shard (ceil(n_total / world)
+        rounded up to the 2-MiB allocation granule).  Rank r holds rows [r * rows_per_shard, min((r + 1) * rows_per_shard, n_total))."""
+        rps = C.c_uint64(0)
+        check(self._L.radhip_index_peer_create(self._h, rank, world, n_total, C.byref(rps)))
+        return int(rps.value)
+
+    def peer_fill_synth(self, seed: int, mode: int = 1) -> None:
+        check(self._L.radhip_index_peer_fill_synth(self._h, seed, mode))
+
+    def peer_fill_rows(self, rows: np.ndarray) -> None:
+        rows = _lib.as_rows(rows, self.row_bytes) if len(rows) else np.zeros((0, self.row_bytes), np.uint8)
+        check(self._L.radhip_index_peer_fill_rows(self._h, ptr(rows) if rows.shape[0] else None, rows.shape[0]))
+
+    def peer_export(self) -> int:
+        """dmabuf file descriptor of this rank's shard (the caller hands it to the peers and closes it)"""
+        fd = C.c_int(-1)
+        check(self._L.radhip_index_peer_export(self._h, C.byref(fd)))
+        return int(fd.value)
+
+    def peer_import(self, peer_rank: int, fd: int) -> None:
+        check(self._L.radhip_index_peer_import(self._h, peer_rank, fd))
+
+    def peer_seal(self) -> None:
+        """all shards mapped: the index holds the whole corpus from here on (read-only)"""
+        check(self._L.radhip_index_peer_seal(self._h))
+
+    def copy_graph_from(self, src: "DeviceIndex") -> None:
+        """the graph of `src` (same device, same process), device to device"""
+        check(self._L.radhip_index_copy_graph_from(self._h, src._h))
+
     def traversal_capacity(self) -> int:
         """Traversals resident on the device at once (one wavefront each)."""
         n = C.c_uint32(0)
@@ -274,6 +306,12 @@ class DeviceTraversal:
         ms = C.c_double(0)
         check(self._L.radhip_traversal_elapsed_between(self._h, other._h, C.byref(ms)))
         return ms.value
+
+    def launch_interval(self):
+        """(start, end) of the last finished launch in ms on the device's clock since a fixed point of the process"""
+        a, b = C.c_double(0), C.c_double(0)
+        check(self._L.radhip_traversal_launch_interval(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def stats(self) -> TraversalStats:
         arr = (_lib.TravStats * self.nq)()

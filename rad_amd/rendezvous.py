@@ -146,3 +146,54 @@ class TcpGroup:
             except OSError:
                 pass
         self._peers, self._up = [], None
+
+
+def exchange_fds(rank: int, world: int, fd: int, key: str, timeout: float = 120.0) -> List[int]:
+    """Every rank's file descriptor on every rank (the dmabuf descriptors of the row shards of a peer-mapped corpus,
+    rad_amd.device.DeviceIndex.peer_export).  Descriptors cross process boundaries only as SCM_RIGHTS messages over a Unix
+    domain socket: rank 0 listens on the abstract address `\\0radhip-<key>`, collects one descriptor per rank and sends all of
+    them to every rank.  Returns [fd of rank 0, ..., fd of rank world - 1] (this rank's own entry is `fd` itself); the caller
+    closes the received ones after importing them."""
+    if world == 1:
+        return [fd]
+    addr = "\0radhip-" + key
+    if rank == 0:
+        srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        srv.bind(addr)
+        srv.listen(world)
+        srv.settimeout(timeout)
+        conns, fds = [None] * world, [None] * world
+        fds[0] = fd
+        for _ in range(world - 1):
+            c, _a = srv.accept()
+            c.settimeout(timeout)
+            msg, got, _flags, _addr = socket.recv_fds(c, 16, 1)
+            r = struct.unpack("<I", msg[:4])[0]
+            if not (1 <= r < world) or conns[r] is not None or len(got) != 1:
+                raise RuntimeError(f"descriptor exchange: unexpected message from rank {r}")
+            conns[r], fds[r] = c, got[0]
+        srv.close()
+        for r in range(1, world):
+            socket.send_fds(conns[r], [struct.pack("<I", world)], fds)
+            conns[r].close()
+        return fds
+    deadline = time.time() + timeout
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    while True:
+        try:
+            s.connect(addr)
+            break
+        except OSError:
+            if time.time() > deadline:
+                raise TimeoutError(f"rank {rank}: nobody listens on the descriptor exchange {key!r}")
+            time.sleep(0.05)
+    s.settimeout(timeout)
+    socket.send_fds(s, [struct.pack("<I", rank)], [fd])
+    _msg, got, _flags, _addr = socket.recv_fds(s, 16, world)
+    s.close()
+    if len(got) != world:
+        raise RuntimeError(f"descriptor exchange: {len(got)} descriptors for {world} ranks")
+    import os as _os
+    _os.close(got[rank])       # (a duplicate of this rank's own descriptor)
+    got[rank] = fd
+    return list(got)

@@ -226,10 +226,13 @@ class TanimotoRADTraverser:
         from .device import DeviceTraversal
         if n_to_score is None:
             raise ValueError("TanimotoRADTraverser needs n_to_score")
-        if self._trav is None or self._n_to_score != n_to_score:
+        # a run to completion keeps the heavy state per resident row of the kernel (a batch of any size then needs the rows'
+        # 40 GB + 0.8 MB per query at n_to_score = 100k); rounds / timeouts park traversals, which needs state per traversal
+        to_completion = timeout is None and not round_pops
+        if self._trav is None or self._n_to_score != n_to_score or (self._trav.slots != 0 and not to_completion):
             if self._trav is not None:
                 self._trav.close()
-            self._trav = DeviceTraversal(self._dev, self.queries, n_to_score, log_pops=self.log_pops)
+            self._trav = DeviceTraversal(self._dev, self.queries, n_to_score, log_pops=self.log_pops, slots=to_completion)
             self._n_to_score = n_to_score
         t0 = time.time()
         if timeout is None and not round_pops:
@@ -273,3 +276,5 @@ class TanimotoRADTraverser:
         if self._trav is not None:
             self._trav.close()
             self._trav = None
+
+    close = shutdown

@@ -49,8 +49,21 @@ def test_bench_json_contract(gpu):
     done, total = j["parity_sample"].split("/")
     assert done == total and int(total) > 0                      # the oracle's sample equals the GPU's counters
     assert j["config"]["corpus_mode"] == 2 and j["config"]["graph_recall_at_10_ef128"] > 0.5
-    ref = j["reference_corpus_r01"]
-    assert ref["value"] > 0 and 0 < ref["roofline_frac"] < 1
+    assert j["config"]["expansion_add"] == 400 and j["config"]["graph_recall_at_10_ef400"] >= j["config"]["graph_recall_at_10_ef128"]
+    r = j["roofline"]
+    # launches of consecutive batches overlap: the union of their intervals is at most the sum of their durations
+    assert 0 < r["kernel_busy_ms"] <= r["avg_launch_ms"] * r["launches"] * 1.001
+    assert j["config"]["traversal_state"]["objects"] == 2
+    # the other kernels of the path, the rounds-1-3 graph and BASELINE configs[1] / [4] ride in the same line
+    k = j["kernels"]
+    assert k["scan_8q"]["GB/s"] > 0 and k["gather"]["GB/s"] > 0 and k["topk_8q_k10"]["self_is_nearest"] is True
+    sg = j["secondary_graph"]
+    assert sg["expansion_add"] == 64 and sg["value"] > 0 and 0 < sg["roofline_frac"] < 1
+    c = j["configs"]
+    assert set(c) == {"c1_1M_1024bit_m8", "c4_2M_2048bit_m32_ef400", "notebook_shape_2M_1024bit_m16_ef400"}
+    for leg in c.values():
+        assert leg.get("skipped") or (leg["value"] > 0 and 0 < leg["roofline_frac"] < 1)
+    assert c["c4_2M_2048bit_m32_ef400"].get("skipped") or (c["c4_2M_2048bit_m32_ef400"]["ndim"] == 2048 and c["c4_2M_2048bit_m32_ef400"]["connectivity"] == 32)
 
 
 def test_bench_two_ranks_from_a_bare_invocation(gpu):
@@ -79,3 +92,10 @@ def test_bench_two_ranks_from_a_bare_invocation(gpu):
     assert j2["value"] == j2["replicas"]["value"] and "replicas" in j2["config"]["parallelism"]
     done, total = j2["sharded"]["parity_vs_single_gpu"].split("/")
     assert done == total and int(total) >= 2 * 64                                         # the sharded leg still ran
+    # ... and so did the peer-mapped leg: two rank processes, each with half of the rows, the other half imported through a dmabuf
+    # descriptor that crossed a Unix socket; every sampled traversal equals the one over the rank's whole-corpus index
+    pm = j2["peer_mapped"]
+    assert pm.get("error") is None, pm
+    done, total = pm["parity_vs_whole_corpus_index"].split("/")
+    assert done == total and int(total) >= 2 * 256 and pm["value"] > 0 and pm["rows_per_shard"] % 16384 == 0
+    assert len(pm["index_bytes_per_rank"]) == 2 and pm["remote_share_of_row_reads"] == 0.5

@@ -212,3 +212,73 @@ def test_retrospective_scored_set_and_scoring_interface(gpu, tmp_path):
     trav.traverse(n_workers=1, n_to_score=25)
     assert len(seen) >= 25
     trav.shutdown()
+
+
+def test_http_front_over_a_gpu_built_index(gpu, tmp_path):
+    """SURVEY.md §8f N4 with a GPU behind it: an index BUILT on the GPU -> rad_amd.hnsw_server -> the JSON
+    shapes a RemoteHNSWService client reads (rad/hnsw_server.py:505-511 /neighbors, :538-543 /top-level-nodes, :561-568
+    /health, :604-613 /info), and every answer equal to what the index object itself returns."""
+    from starlette.testclient import TestClient
+    from rad_amd.hnsw_server import create_app
+    n = 300
+    hnsw = _create_test_hnsw(n=n, dim=64, seed=3)
+    db = str(tmp_path / "t.db")
+    _create_test_database(db, n=n)
+    c = TestClient(create_app(hnsw, database_path=db, api_key="k"))
+    hdr = {"Authorization": "Bearer k"}
+    assert c.get("/ping").json() == {"pong": True}
+    assert c.get("/neighbors/0/0").status_code == 401
+    con = sqlite3.connect(db)
+    smi = dict(con.execute("SELECT node_key, smi FROM nodes").fetchall())
+    con.close()
+    for node in (0, 7, n - 1):
+        r = c.get(f"/neighbors/{node}/0", headers=hdr)
+        assert r.status_code == 200
+        j = r.json()
+        assert set(j) == {"node_id", "level", "neighbors", "neighbor_count", "request_id"}
+        flat = [int(x) for x in hnsw.get_neighbors(node, 0)]              # [slot, key, ...] straight from the index
+        assert j["node_id"] == node and j["level"] == 0 and j["neighbor_count"] == len(flat) // 2 > 0
+        assert j["neighbors"][0::2] == flat[0::2]
+        assert j["neighbors"][1::2] == [smi[k] for k in flat[1::2]]        # keys joined to SMILES (rad/hnsw_service.py:256-283)
+    t = c.get("/top-level-nodes", headers=hdr).json()
+    top = [int(x) for x in hnsw.get_top_level_nodes()]
+    assert set(t) == {"top_nodes", "node_count", "cached", "request_id"}
+    assert t["node_count"] == len(top) // 2 and t["top_nodes"][0::2] == top[0::2]
+    h = c.get("/health").json()
+    assert h["status"] == "healthy" and h["hnsw_size"] == n and h["hnsw_max_level"] == hnsw.max_level
+    i = c.get("/info", headers=hdr).json()
+    assert i["hnsw_info"]["size"] == n and i["hnsw_info"]["ndim"] == 64 and i["hnsw_info"]["connectivity"] == 4
+    assert c.get(f"/neighbors/{n}/0", headers=hdr).status_code == 400
+    assert c.get(f"/neighbors/0/{hnsw.max_level + 1}", headers=hdr).status_code == 400
+
+    # a traversal whose neighbour reads go through those routes equals one that asks the index directly
+    from rad_amd.hnsw_service import HNSWService, create_local_hnsw_service
+    from rad_amd.traverser import RADTraverser
+
+    class OverHttp(HNSWService):
+        def get_neighbors(self, node_id, level):
+            return c.get(f"/neighbors/{node_id}/{level}", headers=hdr).json()["neighbors"]
+
+        def get_top_level_nodes(self):
+            return c.get("/top-level-nodes", headers=hdr).json()["top_nodes"]
+
+        def get_hnsw_info(self):
+            return c.get("/info", headers=hdr).json()["hnsw_info"]
+
+        def get_service_info(self):
+            return {"service_type": "OverHttp", "status": "running"}
+
+        def is_healthy(self):
+            return c.get("/health").json()["status"] == "healthy"
+
+        def shutdown(self):
+            pass
+
+    lists = []
+    for svc in (OverHttp(), create_local_hnsw_service(hnsw, database_path=db)):
+        tr = RADTraverser(hnsw_service=svc, scoring_fn=_scoring_fn)
+        tr.prime()
+        tr.traverse(n_workers=1, n_to_score=60)
+        lists.append(list(tr.scored_set))
+        tr.shutdown()
+    assert lists[0] == lists[1] and len(lists[0]) >= 60

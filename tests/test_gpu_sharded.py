@@ -453,3 +453,48 @@ def test_loop_fails_safe(gpu, oracle, monkeypatch, eng):
     assert np.array_equal(sh.results(0)[0], want.slots)
     info = comm.info()
     assert info["comm_count"] == 1 and info["comm_rank"] == 0 and info["rccl_version_code"] > 0 and ":" in info["pci_bus_id"]
+
+
+def test_eight_virtual_ranks_uneven_last_shard_and_an_idle_rank(gpu, oracle, monkeypatch):
+    """EIGHT ranks' worth of step / evaluation kernels in lock step on one GPU, each rank created with its
+    rows only; the corpus size is not divisible by eight (the last shard is longer); traversals differ in length, so some rank
+    has no live traversal left while others still work and keeps stepping with nothing to do.  Every scored list, count and pop log equals the oracle's traversal of the whole corpus."""
+    from rad_amd.device import DeviceIndex, DeviceShard
+    monkeypatch.delenv("RADHIP_SHARD_ENGINE", raising=False)
+    world, n, nts, nq = 8, 20003, 1200, 3
+    X, g, full, Qall = _row_sharded_setup(oracle, n, nts, world, nq, seed=13)
+    full.close()
+    rows = n // world
+    assert n % world != 0
+    shards, idxs = [], []
+    for r in range(world):
+        first = r * rows
+        count = rows if r < world - 1 else n - first
+        idx = DeviceIndex(1024, 8, 16, 48)
+        idx.load_vectors_shard(X[first:first + count], first, n)
+        idx.load_graph(g.levels, g.adj0, g.upper_row, g.adjU, g.max_level, g.entry)
+        idxs.append(idx)
+        shards.append(DeviceShard(idx, r, world, first, count, Qall, nts, log_pops=True))
+    assert shards[-1].index.info().shard_rows == n - 7 * rows > rows
+    # lock step, recording who is live at every step
+    scores = [np.zeros((s.nq, s.width), np.uint32) for s in shards]
+    steps, live_hist = 0, []
+    while True:
+        stepped = [s.step(scores[r]) for r, s in enumerate(shards)]
+        steps += 1
+        live_hist.append([live for _req, live in stepped])
+        if sum(live_hist[-1]) == 0:
+            break
+        req_all = np.stack([req for req, _live in stepped])
+        outs = [s.evaluate(req_all) for s in shards]
+        scores = [sum(outs[k][r] for k in range(world)) for r in range(world)]
+    live_hist = np.array(live_hist)
+    assert steps > 10
+    # some rank has been idle for a stretch while others were still live (traversal lengths differ)
+    idle_while_others_work = ((live_hist == 0) & (live_hist.sum(1, keepdims=True) > 0)).sum(0)
+    assert idle_while_others_work.max() >= 1, idle_while_others_work
+    _check_against_oracle(oracle, shards, g, X, Qall, nq, nts)
+    for s in shards:
+        s.close()
+    for i in idxs:
+        i.close()

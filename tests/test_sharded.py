@@ -121,16 +121,19 @@ def test_sharded_traversal_world2_gloo(tmp_path, oracle):
 
 
 # ------------------------------------------------------------------ row-sharded traversal (north star)
-def _row_worker(rank, world, port, out_path, exchange):
+_ROW_Q = [11, 4000, 8999, 17, 5555, 2, 7001, 333]
+
+
+def _row_worker(rank, world, port, out_path, exchange, n=9000, nq=3):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import rad_oracle as O
     from rad_amd.sharded import RowShardedTraversal
     from sharded_util import OracleRowShard
-    n, ndim, M, cap0, nts, nq = 9000, 1024, 8, 16, 1200, 3
+    ndim, M, cap0, nts = 1024, 8, 16, 1200
     X = O.synth_rows(0, n, n, ndim, 5, 2)
     g = O.synth_graph(n, M, cap0, 21)
-    Qall = X[[11, 4000, 8999, 17, 5555, 2]].copy()            # world * nq queries, rank-major
+    Qall = X[_ROW_Q[:world * nq]].copy()            # world * nq queries, rank-major
     rows = n // world
     first = rank * rows
     count = rows if rank < world - 1 else n - first
@@ -217,3 +220,33 @@ def test_stepper_equals_sequential_traversal(oracle):
         assert np.array_equal(r.slots, want.slots) and np.array_equal(r.and_cnt, want.and_cnt) and np.array_equal(r.or_cnt, want.or_cnt)
         assert np.array_equal(r.pop_nodes, want.pop_nodes) and np.array_equal(r.pop_levels, want.pop_levels)
         assert st.status == (1 if len(want.slots) >= nts else 2)
+
+
+def test_row_sharded_traversal_world4_gloo_uneven_shards(tmp_path, oracle):
+    """four ranks over gloo, a corpus that does not divide by four (the last rank holds three rows more),
+    two traversals per rank: every rank stops at the same step and returns the single-index traversal's lists."""
+    import multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world, nq, n, nts = 4, 2, 9003, 1200
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_row_worker, args=(r, world, port, str(tmp_path / f"row{r}.npz"), "gloo", n, nq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    X = oracle.synth_rows(0, n, n, 1024, 5, 2)
+    g = oracle.synth_graph(n, 8, 16, 21)
+    Qall = X[_ROW_Q[:world * nq]]
+    outs = [np.load(tmp_path / f"row{r}.npz") for r in range(world)]
+    assert len({int(o["steps"]) for o in outs}) == 1 and int(outs[0]["steps"]) > 10
+    for r in range(world):
+        for q in range(nq):
+            want = oracle.rad_traverse(g, X, Qall[r * nq + q], nts)
+            z = outs[r]
+            assert np.array_equal(z[f"s{q}"], want.slots), (r, q)
+            assert np.array_equal(z[f"a{q}"], want.and_cnt) and np.array_equal(z[f"o{q}"], want.or_cnt)
+            assert np.array_equal(z[f"pn{q}"], want.pop_nodes) and np.array_equal(z[f"pl{q}"], want.pop_levels)

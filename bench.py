@@ -85,9 +85,11 @@ def parse_args():
     ap.add_argument("--no-kernel-legs", action="store_true", help="skip the K1 scan / K2 gather / top-k measurements of the N = 1 line")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the BASELINE configs[1] / configs[4] legs of the N = 1 line")
     ap.add_argument("--config-budget-s", type=float, default=150.0, help="wall-clock budget of the configs legs together")
-    ap.add_argument("--table", choices=["auto", "hash", "group"], default="auto",
-                    help="visited/scored table of the traversal kernel (auto = the library's default, the per-slot hash table; "
-                         "group = the grouped table over the graph-locality layout, measured slower: profiles/r02)")
+    ap.add_argument("--table", choices=["auto", "hash", "group", "local"], default="local",
+                    help="visited/scored table of the traversal kernel: local (default since round 4) = the bucket table with a node's home "
+                         "bucket taken from its graph-locality layout id (+7 % at 100M rows: profiles/r04), auto = the library's own choice "
+                         "(the slot-hashed bucket table), group = the grouped table (2 bits per node; fewer requests, more instructions: a draw), "
+                         "hash = one 8-byte entry per probe")
     ap.add_argument("--no-reference-corpus", action="store_true", help="skip the round-1 corpus leg (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work the cpu_baseline sample should take at least")
@@ -210,7 +212,7 @@ def build_index(args, mode, device, layout=True):
                 np.savez(cache, levels=levels, adj0=adj0, upper_row=upper_row, adjU=adjU, max_level=int(inf.max_level), entry=int(inf.entry), t_build=t_build)
                 note(f"graph saved to {cache}")
     info = None
-    if layout and args.table == "group":
+    if layout and args.table in ("group", "local"):
         info = idx.optimize_layout()
     return idx, t_build, info
 
@@ -241,7 +243,7 @@ def run_traversal_leg(args, idx, batches, steps, warmup, barrier, overlap=True):
     longest traversals running alone: ~130 ms whatever its size).  The pipeline is empty before the clock starts and is
     drained before it stops: exactly `steps` batches are started and finished inside the timed region."""
     from rad_amd.device import DeviceTraversal
-    n_obj = 2 if (overlap and steps + warmup > 1) else 1
+    n_obj = min(2, getattr(args, "objects", 2)) if (overlap and steps + warmup > 1) else 1
     objs = [DeviceTraversal(idx, batches[0], args.n_to_score, slots=True, own_stream=n_obj > 1) for _ in range(n_obj)]
     note(f"traversal state for {n_obj} x {objs[0].nq} traversals allocated ({sum(o.state_bytes() for o in objs) / 1e9:.1f} GB, kernel {objs[0].kernel}, "
          f"table {objs[0].table}, {objs[0].slots or objs[0].nq} rows' worth of tables)")
@@ -868,7 +870,8 @@ def main():
     def barrier():
         grp.barrier()
 
-    if args.table != "auto":
+    # (--mode sharded: the locality layout — pair rows, twice the adjacency — would only serve rank 0's parity reference)
+    if args.table != "auto" and not (args.mode == "sharded" and args.table == "local"):
         os.environ["RADHIP_TABLE"] = args.table
     n = args.n
     if args.mode == "sharded":
@@ -888,21 +891,26 @@ def main():
         from rad_amd._lib import RadHipError, E_NOMEM
         from rad_amd.device import DeviceTraversal
         cap = idx.traversal_capacity()
-        for mult in (4.0, 3.0, 2.0, 1.5, 1.0):
+        # two objects (overlapped launches) with four resident rounds each when there is room; beside a corpus that fills most of the
+        # device (1B rows: 202 GB) one object with as many rounds as fit
+        plans = ([] if args.no_overlap else [(4.0, 2), (3.0, 2), (2.0, 2)]) + [(4.0, 1), (3.0, 1), (2.0, 1), (1.5, 1), (1.0, 1)]
+        for mult, n_obj in plans:
             args.nq = int(cap * mult)
             probes = []
             try:
                 q0 = idx.read_vectors(0, args.nq)
-                for _ in range(1 if args.no_overlap else 2):
+                for _ in range(n_obj):
                     probes.append(DeviceTraversal(idx, q0, args.n_to_score, slots=True))
+                args.objects = n_obj
                 break
             except RadHipError as e:
-                if e.code != E_NOMEM or mult == 1.0:
+                if e.code != E_NOMEM or (mult, n_obj) == plans[-1]:
                     raise
             finally:
                 for p_ in probes:
                     p_.close()
         args.nq = int(grp.allreduce([args.nq], "min")[0])       # the same batch size on every rank
+        args.objects = int(grp.allreduce([getattr(args, "objects", 2)], "min")[0])
     # replicas / single GPU: every rank runs its OWN query batches (the queries are what is split)
     batches = query_batches(idx, n_batches, args.nq, n, 4242 + rank)
     leg = run_traversal_leg(args, idx, batches, args.steps, args.warmup, barrier, overlap=not args.no_overlap)
@@ -1097,7 +1105,7 @@ def main():
             # the graph rounds 1-3 benched (expansion_add 64: a lighter build, more new nodes per expansion), on the same kernel
             try:
                 a2 = argparse.Namespace(**vars(args)); a2.expansion_add = args.secondary_expansion_add
-                idx2, tb2, _ = build_index(a2, args.corpus_mode, local_rank, layout=(args.table == "group"))
+                idx2, tb2, _ = build_index(a2, args.corpus_mode, local_rank, layout=(args.table in ("group", "local")))
                 st2 = min(args.steps, 4)
                 b2 = query_batches(idx2, 1 + st2, args.nq, n, 4242)
                 leg2 = run_traversal_leg(a2, idx2, b2, st2, 1, lambda: None, overlap=not args.no_overlap)

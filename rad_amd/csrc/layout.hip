@@ -27,7 +27,13 @@
 #include <new>
 #include <thread>
 
-#define RH_LAYOUT_GROUP 384u
+// ids per block: 384 = the grouped table's group (8 chunks of 48 ids to a 128-B line).  RADHIP_LAYOUT_GROUP overrides it for
+// the locality-hashed bucket table, whose line holds 8 ids (experiments: profiles/r04)
+static uint32_t layout_group() {
+    static const uint32_t g = [] { const char *e = getenv("RADHIP_LAYOUT_GROUP"); const int v = e ? atoi(e) : 0; return (v >= 4 && v <= 4096) ? (uint32_t)v : 384u; }();
+    return g;
+}
+#define RH_LAYOUT_GROUP (layout_group())
 #define LG_MAXC 32
 
 namespace {

@@ -32,6 +32,7 @@ int rh_trav4_launch_sharded(uint32_t grid, hipStream_t st, const TravParams &P) 
 int rh_trav4_launch(int table, bool wide, bool slot, int lpr, uint32_t grid, hipStream_t st, const TravParams &P) {
     if (table == RH_T4_GROUPED) return rh_trav4_launch_grouped(wide, slot, lpr, grid, st, P);
     if (table == RH_T4_BUCKET) return rh_trav4_launch_bucket(wide, slot, lpr, grid, st, P);
+    if (table == RH_T4_LOCAL) return rh_trav4_launch_local(wide, slot, lpr, grid, st, P);
     if (wide || slot) RH_FAIL(RADHIP_E_STATE, "the hash-table form of trav4_kernel has no wide-row / per-slot variant");
     return rh_trav4_launch_hash(lpr, grid, st, P);
 }

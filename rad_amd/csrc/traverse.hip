@@ -501,6 +501,7 @@ struct radhip_traversal {
     bool wide = false;   // ... its WIDE form: adjacency rows of 17..64 slots, walked in chunks of 16
     bool use_gt = false; // grouped visited/scored table (needs the index's graph-locality layout)
     bool use_bt = false; // bucket table: 16-B buckets of four entries, one request per probe (trav4_kernel's default)
+    bool use_local = false;   // ... hashed by the graph-locality layout id instead of the slot (RADHIP_TABLE=local; needs the layout)
     size_t bt_bytes = 0;
     uint32_t epoch_max = EPOCH_LIMIT - 1u;   // last usable epoch of the table in use
     bool sharded = false; // the row-sharded form of trav4_kernel (shard.hip): stepped, never run()
@@ -633,7 +634,7 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
     {   // RADHIP_TABLE=group on an index without a layout: compute one first (how the parity suites cover
         // the grouped table on every graph they build)
         const char *e = getenv("RADHIP_TABLE");
-        if (e && e[0] == 'g' && !idx->layout_valid) RH_TRY(rh_optimize_layout_locked(idx, 0));
+        if (e && (e[0] == 'g' || e[0] == 'l') && !idx->layout_valid) RH_TRY(rh_optimize_layout_locked(idx, 0));
     }
     radhip_traversal *t = new (std::nothrow) radhip_traversal();
     if (!t) RH_FAIL(RADHIP_E_NOMEM, "out of host memory");
@@ -719,10 +720,16 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
         const bool force_hash = e && e[0] == 'h';
         t->use_bt = t->use4 && !t->use_gt && !sharded && !force_hash;
         P.bt_log2 = std::max<uint32_t>(6, log2_ceil((scored_cap * 5 + 7) / 8));
+        // (the locality-hashed form gives every layout id a bucket of its own: twice the buckets — 2 MB per row of state at
+        // n_to_score = 100k — keep two blocks of 8 ids from meeting on one line too often; measured +5 %, profiles/r04)
+        if (e && e[0] == 'l' && idx->layout_valid && idx->d_adjx0 && t->use4 && !sharded && P.bt_log2 < 28) P.bt_log2 += 1;
+        if (const char *x = getenv("RADHIP_BT_LOG2_ADD")) P.bt_log2 += (uint32_t)std::min(3, std::max(0, atoi(x)));   // (experiments: a larger table)
         P.bt_sbits = std::max<uint32_t>(8, log2_ceil(idx->g_n + 2));
         if (P.bt_sbits > 30 || P.bt_log2 > 28) t->use_bt = false;
         if (t->wide && !t->use_bt && !t->use_gt) { t->wide = false; t->use4 = false; }   // (the WIDE form has no per-slot hash table variant)
         if (t->use_bt) t->epoch_max = (1u << (31u - P.bt_sbits)) - 1u;
+        // the locality-hashed form of the bucket table: same entries, the home bucket comes from the layout id (pair rows)
+        t->use_local = t->use_bt && e && e[0] == 'l' && idx->layout_valid && idx->d_adjx0;
         P.adjx0 = idx->d_adjx0; P.adjxU = idx->d_adjxU; P.topx = idx->d_topx; P.lid = idx->d_lid;
     }
     // RADHIP_TRAV_SLOTS: tables, key pool, run table and mid pool once per RESIDENT ROW of trav4_kernel instead of once per
@@ -867,7 +874,7 @@ static int trav_enqueue(radhip_traversal *t) {
     }
     RH_HIP(hipEventRecord(t->ev0, st));
     if (t->use4) {
-        RH_TRY(rh_trav4_launch(t->use_gt ? RH_T4_GROUPED : t->use_bt ? RH_T4_BUCKET : RH_T4_HASH, t->wide, t->P.slots != 0u, (int)idx->lpr, grid4, st, t->P));
+        RH_TRY(rh_trav4_launch(t->use_gt ? RH_T4_GROUPED : t->use_local ? RH_T4_LOCAL : t->use_bt ? RH_T4_BUCKET : RH_T4_HASH, t->wide, t->P.slots != 0u, (int)idx->lpr, grid4, st, t->P));
     } else {
         switch (idx->lpr) {
             case 1: hipLaunchKernelGGL((trav_kernel<1>), dim3(t->nq), dim3(64), 0, st, t->P); break;
@@ -1386,5 +1393,5 @@ extern "C" int radhip_traversal_resident_capacity(radhip_index_t *idx, uint32_t 
 // 4 = trav4_kernel (four traversals per wavefront), 1 = trav_kernel
 extern "C" int radhip_traversal_kernel(const radhip_traversal_t *t) { return t ? (t->use4 ? 4 : 1) : 0; }
 // 1 = grouped visited/scored table (2 bits per node, keyed by the graph-locality layout), 0 = per-slot hash table
-extern "C" int radhip_traversal_table(const radhip_traversal_t *t) { return t ? (t->use_gt ? 1 : t->use_bt ? 2 : 0) : -1; }
+extern "C" int radhip_traversal_table(const radhip_traversal_t *t) { return t ? (t->use_gt ? 1 : t->use_local ? 3 : t->use_bt ? 2 : 0) : -1; }
 

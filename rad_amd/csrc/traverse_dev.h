@@ -225,7 +225,7 @@ __device__ __forceinline__ uint32_t key_slot(unsigned long long key) {
 }
 
 // ---- trav4_kernel (traverse4.inc) is instantiated in trav4_*.hip; traverse.hip launches it through these
-enum { RH_T4_HASH = 0, RH_T4_BUCKET = 1, RH_T4_GROUPED = 2 };
+enum { RH_T4_HASH = 0, RH_T4_BUCKET = 1, RH_T4_GROUPED = 2, RH_T4_LOCAL = 3 };
 // table: RH_T4_*; wide: adjacency rows of 17..64 slots; slot: heavy state per resident row (P.slots) instead of per traversal
 int rh_trav4_launch(int table, bool wide, bool slot, int lpr, uint32_t grid, hipStream_t st, const TravParams &P);
 int rh_trav4_launch_sharded(uint32_t grid, hipStream_t st, const TravParams &P);
@@ -234,4 +234,5 @@ int rh_trav4_occupancy(int lpr, int *per_cu);
 int rh_trav4_launch_hash(int lpr, uint32_t grid, hipStream_t st, const TravParams &P);
 int rh_trav4_launch_bucket(bool wide, bool slot, int lpr, uint32_t grid, hipStream_t st, const TravParams &P);
 int rh_trav4_launch_grouped(bool wide, bool slot, int lpr, uint32_t grid, hipStream_t st, const TravParams &P);
+int rh_trav4_launch_local(bool wide, bool slot, int lpr, uint32_t grid, hipStream_t st, const TravParams &P);
 uint32_t rh_trav4_staging_capacity();

@@ -376,8 +376,9 @@ class DeviceTraversal:
     @property
     def table(self) -> str:
         """'bucket' (16-B buckets of four entries, one request per probe: the four-per-wavefront kernel's default),
-        'grouped' (2 bits per node, keyed by the index's graph-locality layout) or 'hash' (one 8-byte entry per probe)."""
-        return {1: "grouped", 2: "bucket"}.get(int(self._L.radhip_traversal_table(self._h)), "hash")
+        'local' (the bucket table with a node's home bucket taken from its graph-locality layout id: the ids of a layout block share
+        a 128-B line), 'grouped' (2 bits per node, keyed by the layout) or 'hash' (one 8-byte entry per probe)."""
+        return {1: "grouped", 2: "bucket", 3: "local"}.get(int(self._L.radhip_traversal_table(self._h)), "hash")
 
     @property
     def kernel(self) -> str:

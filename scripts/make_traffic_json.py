@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/traffic_latest.json from one PMC session (scripts/profile_r03.sh): HBM bytes per launch of the traversal
+"""profiles/traffic_latest.json from one PMC session (scripts/profile_r04.sh): HBM bytes per launch of the traversal
 kernel from the memory-side counters, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950
 (FETCH_SIZE x 2; cross-checked against TCC_EA0_RDREQ x 128 B), requests and instructions per expansion.
     python scripts/make_traffic_json.py <session dir>   (run on the box: it asks the library for its build id)"""
@@ -31,9 +31,9 @@ evals = bj["evals_per_s"] * bj["ms_per_step"] * 1e-3
 alg = bj["roofline"]["algorithmic_bytes_per_launch"]
 out = {
     "build_id": _lib.build_id(), "traverse_build_id": _lib.traverse_build_id(), "kernel": kname, "table": bj["roofline"]["table"], "graph": "built", "corpus_mode": bj["config"]["corpus_mode"],
-    "n": bj["config"]["rows"], "nq": bj["config"]["nq_per_gpu"], "n_to_score": bj["config"]["n_to_score"],
+    "n": bj["config"]["rows"], "nq": bj["config"]["nq_per_gpu"], "n_to_score": bj["config"]["n_to_score"], "expansion_add": bj["config"].get("expansion_add", 64),
     "method": "rocprofv3 -f csv --kernel-trace --pmc <group> in separate passes over `python3 bench.py --no-cpu-baseline --no-reference-corpus "
-              "--steps 1 --warmup 0` (scripts/profile_r03.sh), summed per kernel on the box; FETCH_SIZE x 2 per MI355X_MICROARCH.md "
+              "--steps 1 --warmup 0` (scripts/profile_r04.sh), summed per kernel on the box; FETCH_SIZE x 2 per MI355X_MICROARCH.md "
               "(= TCC_EA0_RDREQ x 128 B when every read is a 128-B request); WRITE_SIZE x 1024",
     "fetch_size_kb": ctr["FETCH_SIZE"], "write_size_kb": ctr["WRITE_SIZE"],
     "read_requests_128B": ctr.get("TCC_EA0_RDREQ"), "read_requests_32B": ctr.get("TCC_EA0_RDREQ_32B"),

@@ -36,15 +36,17 @@ def pytest_generate_tests(metafunc):
     # with that kernel on the grouped visited table (the library computes a graph-locality layout for
     # whatever graph the test installed); kernels that have no grouped variant keep the hash table
     if "trav_mode" in metafunc.fixturenames:
-        metafunc.parametrize("trav_mode", ["auto", "trav4", "trav4-grouped"], indirect=True)
+        metafunc.parametrize("trav_mode", ["auto", "trav4", "trav4-grouped", "trav4-local"], indirect=True)
 
 
 @pytest.fixture
 def trav_mode(request, monkeypatch):
-    if request.param in ("trav4", "trav4-grouped"):
+    if request.param in ("trav4", "trav4-grouped", "trav4-local"):
         monkeypatch.setenv("RADHIP_TRAV", "4")
     if request.param == "trav4-grouped":
         monkeypatch.setenv("RADHIP_TABLE", "group")
+    elif request.param == "trav4-local":      # the bucket table hashed by the layout id (round 4)
+        monkeypatch.setenv("RADHIP_TABLE", "local")
     else:
         monkeypatch.delenv("RADHIP_TABLE", raising=False)
     return request.param

@@ -97,7 +97,7 @@ def _check_traversal(oracle, idx, graph, X, Q, n_to_score):
 
 
 @pytest.mark.parametrize("grid,static", [(1, "0"), (2, "0"), (3, "1")])
-@pytest.mark.parametrize("table", ["bucket", "hash", "group"])
+@pytest.mark.parametrize("table", ["bucket", "hash", "group", "local"])
 def test_rows_take_traversals_from_the_counter(gpu, oracle, monkeypatch, grid, static, table):
     """trav4_kernel launches as many wavefronts as the device holds resident and their rows take the traversals of the batch
     one after the other; a grid of one or two wavefronts (test hook) makes every row work through many traversals of

@@ -35,7 +35,7 @@ def _check(t, want, nq, logs=True):
 
 
 @pytest.mark.parametrize("slots,grid,epoch_max", [(4, 1, None), (8, 2, None), (8, 2, 2), (12, 3, 1), (4, 1, 3)])
-@pytest.mark.parametrize("table", ["bucket", "group"])
+@pytest.mark.parametrize("table", ["bucket", "group", "local"])
 def test_slots_fewer_than_traversals(gpu, oracle, monkeypatch, slots, grid, epoch_max, table):
     """37 traversals of different lengths on 4 / 8 / 12 rows' worth of state: every row takes several traversals one after the
     other and reuses its tables under a new epoch; with one, two or three epochs the rows clear their own tables in between
@@ -56,7 +56,7 @@ def test_slots_fewer_than_traversals(gpu, oracle, monkeypatch, slots, grid, epoc
     Q[3] = 0
     want = [oracle.rad_traverse(g, X, Q[i], nts) for i in range(nq)]
     t = DeviceTraversal(idx, Q, nts, log_pops=True, slots=True)
-    assert t.kernel == "trav4_kernel" and t.slots == slots
+    assert t.kernel == "trav4_kernel" and t.slots == slots and t.table == {"group": "grouped"}.get(table, table)
     assert t.run() == 0
     _check(t, want, nq)
     # a second and a third batch on the same object: the rows' epochs carry on from where the last batch left them

@@ -81,6 +81,9 @@ def parse_args():
                     help="N = 1: a second, shorter leg on a graph built with this expansion_add (0 = skip)")
     ap.add_argument("--graph-cache", default="", help="profiling sessions: .npz the built graph is saved to / loaded from, so that every "
                                                        "rocprofv3 pass does not build it again (the graph is the same; only setup time changes)")
+    ap.add_argument("--chain", type=int, default=10,
+                    help="steps (batches) chained into ONE launch of the traversal kernel: a launch ends with its longest traversals running "
+                         "alone (~150 ms whatever its size), so the tail is paid once per chain (0 = the two-object pipeline of overlapped launches)")
     ap.add_argument("--no-overlap", action="store_true", help="one traversal object, one launch after the other (A/B against the two-stream pipeline)")
     ap.add_argument("--no-kernel-legs", action="store_true", help="skip the K1 scan / K2 gather / top-k measurements of the N = 1 line")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the BASELINE configs[1] / configs[4] legs of the N = 1 line")
@@ -235,14 +238,77 @@ def union_ms(intervals):
     return tot + ((cur_e - cur_s) if cur_e is not None else 0.0)
 
 
+def run_chained_leg(args, idx, batches, steps, warmup, barrier):
+    """`steps` timed steps with up to --chain of them per LAUNCH: one traversal object whose batch is chain x nq traversals, state per
+    resident row of the kernel, a ring of scored lists (radhip_traversal_create_ring).  Rows take the traversals of the whole
+    chain from one counter, so a step's longest traversals finish beside the next step's instead of alone on the device.  Every
+    traversal of every step is computed and counted; the scored lists that are still readable at the end are those of the last
+    `ring` traversals (>= the last step: the parity sample reads them).  The warm-up steps are a launch of their own."""
+    from rad_amd.device import DeviceTraversal
+    nq = batches[0].shape[0]
+    chain = max(1, min(args.chain, max(steps, warmup)))
+    first = np.concatenate([batches[i % len(batches)] for i in range(chain)])
+    obj, ring = None, 0
+    from rad_amd._lib import RadHipError, E_NOMEM
+    for ring in (2 * nq, nq):            # lists of the last two steps when there is room, else of the last one
+        try:
+            obj = DeviceTraversal(idx, first, args.n_to_score, list_ring=ring)
+            break
+        except RadHipError as e:
+            if e.code != E_NOMEM or ring == nq:
+                raise
+    note(f"traversal state for chains of {chain} x {nq} traversals allocated ({obj.state_bytes() / 1e9:.1f} GB, kernel {obj.kernel}, table {obj.table}, "
+         f"{obj.slots or obj.nq} rows' worth of tables, ring of {obj.list_ring or obj.nq} scored lists)")
+    acc = {"pops": 0, "evals": 0, "nbrs": 0, "k_ms": [], "iv": []}
+
+    def launch(first_b, n_b, timed):
+        q = np.concatenate(batches[first_b:first_b + n_b]) if n_b > 1 else batches[first_b]
+        obj.reset(q)
+        assert obj.run(0) == 0
+        if timed:
+            st = obj.stats()
+            ms, launches = obj.kernel_time()
+            acc["k_ms"].append(ms / max(launches, 1)); acc["iv"].append(obj.launch_interval())
+            acc["pops"] += int(st.n_pops.sum()); acc["evals"] += int(st.n_scored.sum()); acc["nbrs"] += int(st.n_nbr.sum())
+            return st
+        return None
+
+    b = 0
+    while b < warmup:
+        c = min(chain, warmup - b); launch(b, c, False); b += c
+    note("warm-up done")
+    barrier()
+    t0 = time.perf_counter()
+    last, last_n = None, 0
+    while b < warmup + steps:
+        c = min(chain, warmup + steps - b)
+        last, last_n = launch(b, c, True), c
+        b += c
+    barrier()
+    elapsed = time.perf_counter() - t0
+    note(f"{steps} timed steps done in {len(acc['k_ms'])} launch(es) ({elapsed / max(steps, 1) * 1e3:.0f} ms per step)")
+    lo = (last_n - 1) * nq                              # the last step's traversals within the last launch
+    sl = slice(lo, lo + nq)
+    last_step = type(last)(*[None if v is None else v[sl] for v in (last.n_scored, last.n_pops, last.n_nbr, last.status, last.n_repivot, last.n_flush, last.n_remid, last.n_upper)])
+    out = {"elapsed": elapsed, "pops": acc["pops"], "evals": acc["evals"], "nbrs": acc["nbrs"], "k_ms": acc["k_ms"], "launches": len(acc["k_ms"]),
+           "busy_ms": union_ms(acc["iv"]), "objects": 1, "slots": obj.slots, "chain": chain, "list_ring": obj.list_ring,
+           "kernel": obj.kernel, "table": obj.table, "state_bytes": obj.state_bytes(), "last_stats": last_step,
+           "last_hashes": obj.result_hashes(lo, nq),
+           "remids": float(last_step.n_remid.mean()), "repivots": float(last_step.n_repivot.mean()), "flushes": float(last_step.n_flush.mean())}
+    obj.close()
+    return out
+
+
 def run_traversal_leg(args, idx, batches, steps, warmup, barrier, overlap=True):
-    """`steps` timed steps of the single-GPU hot path on this rank's index.  One step = one batch: re-arm (query upload; the
+    """(--chain 0) `steps` timed steps of the single-GPU hot path on this rank's index.  One step = one batch: re-arm (query upload; the
     rows' epochs make table reuse free) + one launch of the traversal kernel to completion of the batch.  The traversal
     state lives per resident ROW of the kernel (RADHIP_TRAV_SLOTS) and two objects on two streams take the batches in turn,
     so that the next batch's wavefronts start while the last traversals of this one still run (a launch ends with its
     longest traversals running alone: ~130 ms whatever its size).  The pipeline is empty before the clock starts and is
     drained before it stops: exactly `steps` batches are started and finished inside the timed region."""
     from rad_amd.device import DeviceTraversal
+    if getattr(args, "chain", 0) > 1 and overlap and steps > 1:
+        return run_chained_leg(args, idx, batches, steps, warmup, barrier)
     n_obj = min(2, getattr(args, "objects", 2)) if (overlap and steps + warmup > 1) else 1
     objs = [DeviceTraversal(idx, batches[0], args.n_to_score, slots=True, own_stream=n_obj > 1) for _ in range(n_obj)]
     note(f"traversal state for {n_obj} x {objs[0].nq} traversals allocated ({sum(o.state_bytes() for o in objs) / 1e9:.1f} GB, kernel {objs[0].kernel}, "
@@ -304,7 +370,8 @@ def roofline_of(leg, B):
     return {"bound": "hbm", "kernel": leg["kernel"], "table": leg["table"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms,
             "kernel_busy_ms": busy, "kernel_busy_ms_per_launch": busy / max(leg["launches"], 1),
-            "accounting": "achieved = algorithmic bytes of all timed launches / union of their HIP-event intervals (launches of consecutive batches overlap on two streams)",
+            "accounting": "achieved = algorithmic bytes of all timed launches / union of their HIP-event intervals (= their sum when launches do not overlap: "
+                          "--chain; launches of consecutive batches overlap on two streams with --chain 0)",
             "achieved_by_avg_launch_duration": alg / (avg_ms * 1e-3) / 1e9,
             "launch_ms_median": pctl(leg["k_ms"], 50), "launch_ms_p10": pctl(leg["k_ms"], 10), "launch_ms_p90": pctl(leg["k_ms"], 90),
             "launches": leg["launches"]}
@@ -338,9 +405,11 @@ def kernel_legs(idx, n, B):
             c = min(chunk, n - f)
             idx.scan(q[:nq], f, c)
             ms += L.radhip_last_kernel_ms()
-        gbs = n * B / (ms * 1e-3) / 1e9
+        # N x B per pass, the (and, or) outputs included when they are written (they are: 8 B per query and row)
+        gbs = n * (B + 8 * nq) / (ms * 1e-3) / 1e9
         out[f"scan_{nq}q"] = {"ms": ms, "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS, "G_evals_per_s": n * nq / (ms * 1e-3) / 1e9,
-                              "bytes": "rows read once per pass (N x B); + 8 B per (query, row) written"}
+                              "rows_only_GB/s": n * B / (ms * 1e-3) / 1e9,
+                              "bytes": "rows read once per pass (N x B) + 8 B per (query, row) written (SURVEY.md §8d: outputs count when they are written)"}
     rng = np.random.default_rng(0)
     m = 20_000_000
     slots = rng.integers(0, n, m).astype(np.uint32)
@@ -893,14 +962,19 @@ def main():
         cap = idx.traversal_capacity()
         # two objects (overlapped launches) with four resident rounds each when there is room; beside a corpus that fills most of the
         # device (1B rows: 202 GB) one object with as many rounds as fit
-        plans = ([] if args.no_overlap else [(4.0, 2), (3.0, 2), (2.0, 2)]) + [(4.0, 1), (3.0, 1), (2.0, 1), (1.5, 1), (1.0, 1)]
+        chained = args.chain > 1 and not args.no_overlap and args.steps > 1
+        plans = ([] if (args.no_overlap or chained) else [(4.0, 2), (3.0, 2), (2.0, 2)]) + [(4.0, 1), (3.0, 1), (2.0, 1), (1.5, 1), (1.0, 1)]
         for mult, n_obj in plans:
             args.nq = int(cap * mult)
             probes = []
             try:
-                q0 = idx.read_vectors(0, args.nq)
-                for _ in range(n_obj):
-                    probes.append(DeviceTraversal(idx, q0, args.n_to_score, slots=True))
+                if chained:        # one object: the rows' tables + a ring of one step's scored lists + a chain's headers and queries
+                    c_ = max(1, min(args.chain, max(args.steps, args.warmup)))
+                    probes.append(DeviceTraversal(idx, idx.read_vectors(0, c_ * args.nq), args.n_to_score, list_ring=args.nq))
+                else:
+                    q0 = idx.read_vectors(0, args.nq)
+                    for _ in range(n_obj):
+                        probes.append(DeviceTraversal(idx, q0, args.n_to_score, slots=True))
                 args.objects = n_obj
                 break
             except RadHipError as e:
@@ -939,8 +1013,12 @@ def main():
         "corpus_mode": args.corpus_mode, "expansion_add": args.expansion_add, "graph_build_s": t_build,
         "graph_recall_at_10_ef128": recall, "graph_recall_at_10_ef400": recall400,
         "traversal_state": {"objects": leg["objects"], "rows_with_tables_per_object": leg["slots"] or args.nq, "bytes": leg["state_bytes"],
-                            "what": "tables / key pool / run table per resident row of the kernel (RADHIP_TRAV_SLOTS), query + header + scored list per traversal; "
-                                    "two objects on two streams take the batches in turn (radhip_traversal_start / _finish)"},
+                            "steps_per_launch": leg.get("chain", 1), "scored_list_ring": leg.get("list_ring", 0),
+                            "what": "tables / key pool / run table per resident row of the kernel (RADHIP_TRAV_SLOTS), query + header per traversal; "
+                                    + ("up to --chain steps go into ONE launch (rows take the traversals of the whole chain from one counter: a step's longest "
+                                       "traversals finish beside the next step's), scored lists in a ring that keeps the last step's (radhip_traversal_create_ring)"
+                                       if leg.get("chain", 1) > 1 else
+                                       "a scored list per traversal; two objects on two streams take the batches in turn (radhip_traversal_start / _finish)")},
         "layout": None if lay is None else {"seconds": lay.seconds, "groups_per_row": lay.groups_per_row, "degree": lay.degree},
         "parallelism": "single GPU",
     }

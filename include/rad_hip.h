@@ -272,6 +272,18 @@ int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queries, uint32_
 int radhip_traversal_destroy(radhip_traversal_t *t);
 /* re-arm the same state for a new set of nq queries (bench steps) */
 int radhip_traversal_reset(radhip_traversal_t *t, const uint8_t *queries);
+/* ... or its first `count` (<= nq) traversals only; the others rest */
+int radhip_traversal_reset_count(radhip_traversal_t *t, const uint8_t *queries, uint32_t count);
+/* CHAINED BATCHES (round 4).  A launch ends with its longest traversals running alone (~150 ms whatever its size), so several
+ * batches go into ONE launch: one object of nq = batches x traversals, per-row state (RADHIP_TRAV_SLOTS is implied), and a RING
+ * of `list_ring` scored lists (rounded up to a power of two, at least two resident rounds of the kernel): traversal i writes
+ * list i mod ring once traversal i - ring is done with it.  Every traversal's counts stay in the statistics; the scored lists
+ * that can still be read (radhip_traversal_results / _result_hashes) are those of the last `ring` traversals — what a
+ * consumer that drains results as traversals complete would have freed (rad/scored.py:63-85; request_work has no batch
+ * boundary: rad/coordination_service.py:290).  radhip_traversal_list_ring: the ring in use (0 = one list per traversal). */
+int radhip_traversal_create_ring(radhip_index_t *idx, const uint8_t *queries, uint32_t nq, uint64_t n_to_score,
+                                 uint32_t flags, uint32_t list_ring, radhip_traversal_t **out);
+uint32_t radhip_traversal_list_ring(const radhip_traversal_t *t);
 /* advance every unfinished traversal by at most max_pops expansions
  * (0 = run to completion); returns the number still running. */
 int radhip_traversal_run(radhip_traversal_t *t, uint64_t max_pops, uint32_t *out_running);

@@ -111,6 +111,9 @@ SIGNATURES = {
     "radhip_index_peer_seal": (C.c_int, [_P]),
     "radhip_index_copy_graph_from": (C.c_int, [_P, _P]),
     "radhip_traversal_run": (C.c_int, [_P, _U64, C.POINTER(_U32)]),
+    "radhip_traversal_reset_count": (C.c_int, [_P, _P, _U32]),
+    "radhip_traversal_create_ring": (C.c_int, [_P, _P, _U32, _U64, _U32, _U32, C.POINTER(_P)]),
+    "radhip_traversal_list_ring": (_U32, [_P]),
     "radhip_traversal_start": (C.c_int, [_P]),
     "radhip_traversal_finish": (C.c_int, [_P, C.POINTER(_U32)]),
     "radhip_traversal_elapsed_between": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),

@@ -516,6 +516,8 @@ struct radhip_traversal {
     // round 4: heavy state per resident row instead of per traversal (RADHIP_TRAV_SLOTS), and launches that do not wait
     // (radhip_traversal_start / _finish on a stream of the object's own, RADHIP_TRAV_OWN_STREAM)
     uint32_t sn = 0;               // state sets allocated: nq, or the slots
+    uint32_t n_active = 0;         // traversals of the batch that is armed (<= nq: radhip_traversal_reset_count)
+    uint32_t list_ring = 0;        // scored lists allocated when fewer than nq (a power of two): traversal i writes list i mod ring
     size_t slot_epoch_bytes = 0;
     hipStream_t stream = nullptr;  // the index's stream, or the object's own
     bool own_stream = false;
@@ -531,17 +533,24 @@ static uint32_t log2_ceil(uint64_t x) {
 
 static int trav_upload_queries(radhip_traversal *t, const uint8_t *queries) {
     radhip_index *idx = t->idx;
+    const uint32_t na = t->n_active;       // (the first n_active traversals of the object are armed)
     if (queries != t->h_queries.data()) {   // host copy: the capacity fallbacks of run() re-arm the batch themselves
-        try { t->h_queries.assign(queries, queries + (size_t)t->nq * idx->row_bytes); }
+        try { t->h_queries.assign(queries, queries + (size_t)na * idx->row_bytes); }
         catch (...) { RH_FAIL(RADHIP_E_NOMEM, "out of host memory"); }
     }
-    std::vector<uint8_t> padded((size_t)t->nq * idx->row_stride, 0);
-    std::vector<TravHeader> hdr(t->nq);
+    std::vector<uint8_t> padded((size_t)na * idx->row_stride, 0);
+    std::vector<TravHeader> hdr(na);
     memset(hdr.data(), 0, hdr.size() * sizeof(TravHeader));
-    for (uint32_t i = 0; i < t->nq; ++i) {
+    t->P.nq = na;
+    for (uint32_t i = 0; i < na; ++i) {
         memcpy(padded.data() + (size_t)i * idx->row_stride, queries + (size_t)i * idx->row_bytes, idx->row_bytes);
         uint32_t p = 0;
-        for (uint32_t b = 0; b < idx->row_bytes; ++b) p += (uint32_t)__builtin_popcount(queries[(size_t)i * idx->row_bytes + b]);
+        {   // (a chain of ten bench steps is 655360 queries: eight bytes at a time)
+            const uint8_t *row = queries + (size_t)i * idx->row_bytes;
+            uint32_t b = 0;
+            for (; b + 8 <= idx->row_bytes; b += 8) { uint64_t w; memcpy(&w, row + b, 8); p += (uint32_t)__builtin_popcountll(w); }
+            for (; b < idx->row_bytes; ++b) p += (uint32_t)__builtin_popcount(row[b]);
+        }
         hdr[i].qpop = p;
         hdr[i].target = t->n_to_score;
         hdr[i].frontier_key = RH_KEY_INF;
@@ -554,7 +563,7 @@ static int trav_upload_queries(radhip_traversal *t, const uint8_t *queries) {
     if (t->in_flight) RH_FAIL(RADHIP_E_STATE, "the traversal object has a launch in flight: radhip_traversal_finish first");
     hipStream_t st = t->stream;
     RH_HIP(hipMemcpyAsync(t->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, st));
-    RH_HIP(hipMemcpyAsync(t->P.hdr, hdr.data(), t->hdr_bytes, hipMemcpyHostToDevice, st));
+    RH_HIP(hipMemcpyAsync(t->P.hdr, hdr.data(), (size_t)na * sizeof(TravHeader), hipMemcpyHostToDevice, st));
     if (t->P.slots) {
         // per-row epochs live on the device (a row bumps its own when it takes a traversal and clears its own tables when
         // they run out): re-arming a batch touches no table at all
@@ -618,7 +627,7 @@ static int trav_forced_kernel();
 static int trav_capacity_of(radhip_index *idx, bool use4, uint32_t *out);
 
 static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_t nq, uint64_t n_to_score, uint32_t flags,
-                            bool sharded, radhip_traversal_t **out) {
+                            bool sharded, radhip_traversal_t **out, uint32_t list_ring = 0) {
     if (!idx || !queries || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
     if (nq == 0) RH_FAIL(RADHIP_E_INVALID, "nq must be > 0");
     if (n_to_score == 0) RH_FAIL(RADHIP_E_INVALID, "n_to_score must be > 0");
@@ -638,7 +647,7 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
     }
     radhip_traversal *t = new (std::nothrow) radhip_traversal();
     if (!t) RH_FAIL(RADHIP_E_NOMEM, "out of host memory");
-    t->idx = idx; t->nq = nq; t->n_to_score = n_to_score; t->flags = flags; t->sharded = sharded;
+    t->idx = idx; t->nq = nq; t->n_active = nq; t->n_to_score = n_to_score; t->flags = flags; t->sharded = sharded;
     t->stream = idx->stream;
     if ((flags & RADHIP_TRAV_OWN_STREAM) && !sharded) {
         if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) { delete t; (void)hipGetLastError(); RH_FAIL(RADHIP_E_HIP, "hipStreamCreate failed"); }
@@ -755,7 +764,16 @@ static int trav_create_impl(radhip_index_t *idx, const uint8_t *queries, uint32_
     t->bt_bytes = t->use_bt ? (sn << (P.bt_log2 + 2)) * 4 : 0;
     t->ht_bytes = (t->use_gt || t->use_bt) ? 0 : (sn << ht_log2) * 8;
     t->ut_bytes = (sn << ut_log2) * 8;
-    t->scored_bytes = (size_t)nq * scored_cap * sizeof(uint2);
+    // a ring of scored lists for chained batches (per-row state only): traversal i writes list i mod ring, gated on traversal
+    // i - ring being done; at least 4 resident rounds of lists, so that the gate never waits in practice
+    P.list_mask = 0xFFFFFFFFu;
+    if (list_ring && P.slots) {
+        uint32_t r = 1; while (r < list_ring) r <<= 1;
+        if (r < 2u * P.slots) r = 2u * P.slots;
+        { uint32_t r2 = 1; while (r2 < r) r2 <<= 1; r = r2; }
+        if (r < nq) { t->list_ring = r; P.list_mask = r - 1u; }
+    }
+    t->scored_bytes = (size_t)(t->list_ring ? t->list_ring : nq) * scored_cap * sizeof(uint2);
     t->pq_bytes = sn * pq_cap * 8;
     t->stg_bytes = P.slots ? 0 : (size_t)nq * S_CAP * 8;
     // a far run is written by a staging flush (64-256 keys) and stays in the table while it holds a key:
@@ -812,6 +830,15 @@ extern "C" int radhip_traversal_create(radhip_index_t *idx, const uint8_t *queri
                                        uint64_t n_to_score, uint32_t flags, radhip_traversal_t **out) {
     return trav_create_impl(idx, queries, nq, n_to_score, flags, false, out);
 }
+// ... with a RING of scored lists (RADHIP_TRAV_SLOTS only; ignored otherwise): a batch of many resident rounds — several bench
+// steps chained into ONE launch, so that the tail of a launch (its longest traversals running alone) is paid once — keeps the
+// lists of its last `list_ring` traversals (rounded up to a power of two, at least two resident rounds); every traversal's
+// counts stay in the statistics.  What a consumer that drains results as they complete would see (rad/scored.py:63-85).
+extern "C" int radhip_traversal_create_ring(radhip_index_t *idx, const uint8_t *queries, uint32_t nq, uint64_t n_to_score,
+                                            uint32_t flags, uint32_t list_ring, radhip_traversal_t **out) {
+    return trav_create_impl(idx, queries, nq, n_to_score, flags | RADHIP_TRAV_SLOTS, false, out, list_ring);
+}
+extern "C" uint32_t radhip_traversal_list_ring(const radhip_traversal_t *t) { return t ? t->list_ring : 0; }
 
 // ---- the row-sharded form (shard.hip owns the exchange buffers and the loop) ---------------------------------
 int rh_trav_create_sharded(radhip_index *idx, const uint8_t *queries, uint32_t nq, uint64_t n_to_score, uint32_t flags,
@@ -833,13 +860,23 @@ int rh_trav_enqueue_shard_step(radhip_traversal *t) {
 }
 uint64_t rh_trav_graph_gen(const radhip_traversal *t) { return t->graph_gen; }
 
-extern "C" int radhip_traversal_reset(radhip_traversal_t *t, const uint8_t *queries) {
+static int trav_reset_impl(radhip_traversal_t *t, const uint8_t *queries, uint32_t count) {
     if (!t || !queries) RH_FAIL(RADHIP_E_INVALID, "null argument");
+    if (count == 0 || count > t->nq) RH_FAIL(RADHIP_E_RANGE, "a batch of this object holds 1..%u traversals (got %u)", t->nq, count);
     std::lock_guard<std::mutex> lk(t->idx->mu);
     if (t->graph_gen != t->idx->graph_gen)
         RH_FAIL(RADHIP_E_STATE, "the index changed since this traversal object was created: create a new one");
     RH_HIP(hipSetDevice(t->idx->device));
+    if (t->in_flight) RH_FAIL(RADHIP_E_STATE, "the traversal object has a launch in flight: radhip_traversal_finish first");
+    t->n_active = count;
     return trav_upload_queries(t, queries);
+}
+extern "C" int radhip_traversal_reset(radhip_traversal_t *t, const uint8_t *queries) {
+    return trav_reset_impl(t, queries, t ? t->nq : 0);
+}
+// re-arm the first `count` (<= nq) traversals of the object with new queries; the others rest
+extern "C" int radhip_traversal_reset_count(radhip_traversal_t *t, const uint8_t *queries, uint32_t count) {
+    return trav_reset_impl(t, queries, count);
 }
 
 // one launch of the kernel the object is bound to, enqueued on the object's stream between its two events (no wait)
@@ -856,7 +893,7 @@ static int trav_enqueue(radhip_traversal *t) {
 #endif
     // trav4_kernel: as many wavefronts as the device holds resident; their rows take the traversals of the batch from
     // a counter, one after the other (traverse4.inc)
-    uint32_t grid4 = (t->nq + 3u) / 4u;
+    uint32_t grid4 = (t->n_active + 3u) / 4u;
     if (t->use4) {
         if (t->resident4 == 0) { uint32_t c = 0; RH_TRY(trav_capacity_of(idx, true, &c)); t->resident4 = c ? c : 4u; }
         // Rows that take their traversals from the counter: +2-4 % on rows of <= 16 slots (no row waits for the longest of
@@ -877,11 +914,11 @@ static int trav_enqueue(radhip_traversal *t) {
         RH_TRY(rh_trav4_launch(t->use_gt ? RH_T4_GROUPED : t->use_local ? RH_T4_LOCAL : t->use_bt ? RH_T4_BUCKET : RH_T4_HASH, t->wide, t->P.slots != 0u, (int)idx->lpr, grid4, st, t->P));
     } else {
         switch (idx->lpr) {
-            case 1: hipLaunchKernelGGL((trav_kernel<1>), dim3(t->nq), dim3(64), 0, st, t->P); break;
-            case 2: hipLaunchKernelGGL((trav_kernel<2>), dim3(t->nq), dim3(64), 0, st, t->P); break;
-            case 4: hipLaunchKernelGGL((trav_kernel<4>), dim3(t->nq), dim3(64), 0, st, t->P); break;
-            case 8: hipLaunchKernelGGL((trav_kernel<8>), dim3(t->nq), dim3(64), 0, st, t->P); break;
-            default: hipLaunchKernelGGL((trav_kernel<16>), dim3(t->nq), dim3(64), 0, st, t->P); break;
+            case 1: hipLaunchKernelGGL((trav_kernel<1>), dim3(t->n_active), dim3(64), 0, st, t->P); break;
+            case 2: hipLaunchKernelGGL((trav_kernel<2>), dim3(t->n_active), dim3(64), 0, st, t->P); break;
+            case 4: hipLaunchKernelGGL((trav_kernel<4>), dim3(t->n_active), dim3(64), 0, st, t->P); break;
+            case 8: hipLaunchKernelGGL((trav_kernel<8>), dim3(t->n_active), dim3(64), 0, st, t->P); break;
+            default: hipLaunchKernelGGL((trav_kernel<16>), dim3(t->n_active), dim3(64), 0, st, t->P); break;
         }
     }
     RH_HIP(hipGetLastError());
@@ -1031,12 +1068,12 @@ static int trav_grow_upper(radhip_traversal *t) {
 // what a finished launch left: running / failed traversals; the capacity fallbacks re-arm and re-run a batch whose FIRST
 // launch hit a fixed-capacity structure (nothing of it has been returned to the caller yet)
 static int trav_after_launch(radhip_traversal *t, bool first_launch, uint32_t *out_running) {
-    std::vector<TravHeader> hdr(t->nq);
+    std::vector<TravHeader> hdr(t->n_active);
     for (int attempt = 0;; ++attempt) {
-        RH_HIP(hipMemcpy(hdr.data(), t->P.hdr, t->hdr_bytes, hipMemcpyDeviceToHost));
+        RH_HIP(hipMemcpy(hdr.data(), t->P.hdr, (size_t)t->n_active * sizeof(TravHeader), hipMemcpyDeviceToHost));
         uint32_t running = 0;
         int bad = 0;
-        for (uint32_t i = 0; i < t->nq; ++i) {
+        for (uint32_t i = 0; i < t->n_active; ++i) {
             if (hdr[i].status == 0) running++;  // status 3 (intermediate target reached) is parked, not running
             if (hdr[i].status < 0 && !bad) bad = hdr[i].status;
         }
@@ -1157,9 +1194,10 @@ extern "C" int radhip_traversal_stats(const radhip_traversal_t *t, radhip_trav_s
     if (!t || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(t->idx->mu);
     RH_HIP(hipSetDevice(t->idx->device));
-    std::vector<TravHeader> hdr(t->nq);
-    RH_HIP(hipMemcpy(hdr.data(), t->P.hdr, t->hdr_bytes, hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < t->nq; ++i) {
+    std::vector<TravHeader> hdr(t->n_active);
+    RH_HIP(hipMemcpy(hdr.data(), t->P.hdr, (size_t)t->n_active * sizeof(TravHeader), hipMemcpyDeviceToHost));
+    if (t->n_active < t->nq) memset(out + t->n_active, 0, (size_t)(t->nq - t->n_active) * sizeof *out);   // (not armed in this batch)
+    for (uint32_t i = 0; i < t->n_active; ++i) {
         out[i].n_scored = hdr[i].n_scored; out[i].n_pops = hdr[i].n_pops; out[i].n_nbr = hdr[i].n_nbr;
         out[i].n_repivot = hdr[i].n_repivot; out[i].n_flush = hdr[i].n_flush;
         out[i].status = hdr[i].status; out[i].n_remid = (int32_t)hdr[i].n_remid;
@@ -1168,10 +1206,21 @@ extern "C" int radhip_traversal_stats(const radhip_traversal_t *t, radhip_trav_s
     return RADHIP_OK;
 }
 
+// with a ring of scored lists only the lists of the last `ring` traversals of the batch are still there
+static int trav_list_kept(const radhip_traversal *t, uint32_t first, uint32_t count) {
+    if (t->P.list_mask == 0xFFFFFFFFu || t->n_active <= t->list_ring) return RADHIP_OK;
+    if (first < t->n_active - t->list_ring)
+        RH_FAIL(RADHIP_E_STATE, "the scored lists of traversals below %u were overwritten (a ring of %u lists serves this batch of %u): "
+                "their counts are in the statistics", t->n_active - t->list_ring, t->list_ring, t->n_active);
+    (void)count;
+    return RADHIP_OK;
+}
+
 extern "C" int radhip_traversal_results(const radhip_traversal_t *t, uint32_t q, uint32_t *out_slots,
                                         uint32_t *out_and, uint32_t *out_or, uint64_t cap, uint64_t *out_n) {
     if (!t || !out_n) RH_FAIL(RADHIP_E_INVALID, "null argument");
-    if (q >= t->nq) RH_FAIL(RADHIP_E_RANGE, "traversal %u out of range", q);
+    if (q >= t->n_active) RH_FAIL(RADHIP_E_RANGE, "traversal %u out of range", q);
+    RH_TRY(trav_list_kept(t, q, 1));
     std::lock_guard<std::mutex> lk(t->idx->mu);
     RH_HIP(hipSetDevice(t->idx->device));
     TravHeader h;
@@ -1180,7 +1229,7 @@ extern "C" int radhip_traversal_results(const radhip_traversal_t *t, uint32_t q,
     *out_n = h.n_scored;
     if (n == 0) return RADHIP_OK;
     std::vector<uint2> buf(n);
-    RH_HIP(hipMemcpy(buf.data(), t->P.scored + (uint64_t)q * t->P.scored_cap, n * sizeof(uint2), hipMemcpyDeviceToHost));
+    RH_HIP(hipMemcpy(buf.data(), t->P.scored + (uint64_t)(q & t->P.list_mask) * t->P.scored_cap, n * sizeof(uint2), hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < n; ++i) {
         if (out_slots) out_slots[i] = buf[i].x;
         if (out_and) out_and[i] = buf[i].y & 0xFFFFu;
@@ -1198,11 +1247,11 @@ __device__ __forceinline__ unsigned long long th_mix64(unsigned long long x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
     return x ^ (x >> 31);
 }
-__global__ __launch_bounds__(256) void result_hash_kernel(const uint2 *scored, uint64_t scored_cap, const TravHeader *hdr, uint32_t first_q,
+__global__ __launch_bounds__(256) void result_hash_kernel(const uint2 *scored, uint64_t scored_cap, uint32_t list_mask, const TravHeader *hdr, uint32_t first_q,
                                                           unsigned long long *out) {
     const uint32_t q = first_q + blockIdx.x;
     const uint64_t n = hdr[q].n_scored < scored_cap ? hdr[q].n_scored : scored_cap;
-    const uint2 *sc = scored + (uint64_t)q * scored_cap;
+    const uint2 *sc = scored + (uint64_t)(q & list_mask) * scored_cap;
     unsigned long long h = 0;
     for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
         const uint2 e = sc[i];
@@ -1214,7 +1263,8 @@ __global__ __launch_bounds__(256) void result_hash_kernel(const uint2 *scored, u
 
 extern "C" int radhip_traversal_result_hashes(const radhip_traversal_t *t, uint32_t first, uint32_t count, uint64_t *out) {
     if (!t || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
-    if ((uint64_t)first + count > t->nq) RH_FAIL(RADHIP_E_RANGE, "traversals [%u, %u) out of range", first, first + count);
+    if ((uint64_t)first + count > t->n_active) RH_FAIL(RADHIP_E_RANGE, "traversals [%u, %u) out of range", first, first + count);
+    RH_TRY(trav_list_kept(t, first, count));
     if (count == 0) return RADHIP_OK;
     radhip_index *idx = t->idx;
     std::lock_guard<std::mutex> lk(idx->mu);
@@ -1224,7 +1274,7 @@ extern "C" int radhip_traversal_result_hashes(const radhip_traversal_t *t, uint3
     int rc = RADHIP_OK;
     if (hipMemsetAsync(d, 0, (size_t)count * 8, t->stream) != hipSuccess) rc = RADHIP_E_HIP;
     if (rc == RADHIP_OK) {
-        hipLaunchKernelGGL(result_hash_kernel, dim3(count), dim3(256), 0, t->stream, t->P.scored, t->P.scored_cap, t->P.hdr, first, d);
+        hipLaunchKernelGGL(result_hash_kernel, dim3(count), dim3(256), 0, t->stream, t->P.scored, t->P.scored_cap, t->P.list_mask, t->P.hdr, first, d);
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d, (size_t)count * 8, hipMemcpyDeviceToHost, t->stream) != hipSuccess ||
             hipStreamSynchronize(t->stream) != hipSuccess) rc = RADHIP_E_HIP;
     }

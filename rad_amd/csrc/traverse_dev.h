@@ -100,6 +100,7 @@ struct TravParams {
     uint32_t slots;                // 0 = state per traversal
     uint32_t epoch_first, epoch_max;   // epochs a row's table entries can carry (bucket table: 1 .. 2^(31 - bt_sbits) - 1; others 0 .. 126)
     uint32_t *slot_epoch;          // [slots] epoch of the last traversal each row worked on (epoch_first - 1 = cleared tables, nothing yet)
+    uint32_t list_mask;            // 0xFFFFFFFF: one scored list per traversal; else ring - 1: traversal i writes list i & list_mask (SLOT form)
     uint32_t *poplog_nodes;
     uint8_t *poplog_levels;
     uint64_t poplog_cap;

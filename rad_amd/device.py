@@ -254,7 +254,7 @@ class DeviceTraversal:
     """nq independent RAD traversals, Tanimoto-scored, state in HBM (radhip_traversal_t)."""
 
     def __init__(self, index: DeviceIndex, queries: np.ndarray, n_to_score: int, log_pops: bool = False,
-                 slots: bool = False, own_stream: bool = False):
+                 slots: bool = False, own_stream: bool = False, list_ring: int = 0):
         """slots: the heavy state (tables, queue pools) once per resident row of the kernel instead of once per traversal —
         such a batch runs to completion (no max_pops, no set_targets); own_stream: a HIP stream of the object's own, so
         that start() / finish() of two objects overlap."""
@@ -265,8 +265,15 @@ class DeviceTraversal:
         self.n_to_score = int(n_to_score)
         self._h = C.c_void_p()
         flags = (_lib.TRAV_LOG_POPS if log_pops else 0) | (_lib.TRAV_SLOTS if slots else 0) | (_lib.TRAV_OWN_STREAM if own_stream else 0)
-        check(self._L.radhip_traversal_create(index._h, ptr(q), self.nq, self.n_to_score, flags, C.byref(self._h)))
+        if list_ring:
+            # chained batches: per-row state and a ring of scored lists — results() / result_hashes() reach the last `list_ring`
+            # traversals of a batch, stats() all of them
+            check(self._L.radhip_traversal_create_ring(index._h, ptr(q), self.nq, self.n_to_score, flags, int(list_ring), C.byref(self._h)))
+        else:
+            check(self._L.radhip_traversal_create(index._h, ptr(q), self.nq, self.n_to_score, flags, C.byref(self._h)))
         self.slots = int(self._L.radhip_traversal_slots(self._h))   # 0: state per traversal (flag not given, or not applicable)
+        self.list_ring = int(self._L.radhip_traversal_list_ring(self._h))   # 0: one scored list per traversal
+        self.n_active = self.nq
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -280,10 +287,12 @@ class DeviceTraversal:
             pass
 
     def reset(self, queries: np.ndarray) -> None:
+        """re-arm the object with new queries: all nq of them, or the first len(queries) <= nq (the others rest)"""
         q = _lib.as_rows(queries, self.index.row_bytes, "queries")
-        if q.shape[0] != self.nq:
-            raise ValueError(f"reset needs exactly {self.nq} queries")
-        check(self._L.radhip_traversal_reset(self._h, ptr(q)))
+        if not 0 < q.shape[0] <= self.nq:
+            raise ValueError(f"reset takes 1..{self.nq} queries")
+        check(self._L.radhip_traversal_reset_count(self._h, ptr(q), q.shape[0]))
+        self.n_active = q.shape[0]
 
     def run(self, max_pops: int = 0) -> int:
         """Advance every unfinished traversal by at most max_pops expansions
@@ -316,7 +325,7 @@ class DeviceTraversal:
     def stats(self) -> TraversalStats:
         arr = (_lib.TravStats * self.nq)()
         check(self._L.radhip_traversal_stats(self._h, arr))
-        rec = np.frombuffer(arr, dtype=_TRAV_STATS_DTYPE, count=self.nq)   # one view, no per-record Python
+        rec = np.frombuffer(arr, dtype=_TRAV_STATS_DTYPE, count=self.nq)[:self.n_active]   # one view, no per-record Python
         return TraversalStats(rec["n_scored"].astype(np.int64), rec["n_pops"].astype(np.int64),
                               rec["n_nbr"].astype(np.int64), rec["status"].astype(np.int32),
                               rec["n_repivot"].astype(np.int64), rec["n_flush"].astype(np.int64), rec["n_remid"].astype(np.int64),
@@ -335,7 +344,7 @@ class DeviceTraversal:
 
     def result_hashes(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
         """order-sensitive 64-bit hash of the scored lists of traversals [first, first+count), formed on the device"""
-        count = self.nq - first if count is None else count
+        count = self.n_active - first if count is None else count
         out = np.zeros(count, np.uint64)
         check(self._L.radhip_traversal_result_hashes(self._h, first, count, ptr(out)))
         return out

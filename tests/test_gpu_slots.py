@@ -195,3 +195,59 @@ def test_slots_at_a_real_resident_round(gpu, oracle):
     t.close()
     t2.close()
     idx.close()
+
+
+@pytest.mark.parametrize("slots,grid,ring", [(4, 1, 8), (8, 2, 16), (8, 1, 16), (16, 4, 32)])
+@pytest.mark.parametrize("table", ["bucket", "local"])
+def test_chained_batches_on_a_ring_of_scored_lists(gpu, oracle, monkeypatch, slots, grid, ring, table):
+    """Several batches in ONE launch (radhip_traversal_create_ring): 75 traversals on 4 / 8 / 16 rows' worth of state and a ring of
+    8 / 16 / 32 scored lists — every list slot is reused several times, and with so few rows a row regularly draws a traversal
+    whose slot is still being written by a traversal on ANOTHER ROW OF ITS OWN WAVEFRONT (the gate must not block the wavefront).
+    Counts of ALL traversals and the complete lists and pop logs of the last `ring` == oracle; the lists of the earlier ones are
+    refused, not returned stale."""
+    from rad_amd.device import DeviceTraversal
+    from rad_amd._lib import RadHipError
+    monkeypatch.setenv("RADHIP_TRAV", "4")
+    if table != "bucket":
+        monkeypatch.setenv("RADHIP_TABLE", table)
+    monkeypatch.setenv("RADHIP_TEST_SLOTS", str(slots))
+    monkeypatch.setenv("RADHIP_TEST_GRID", str(grid))
+    n, nq, nts = 6000, 75, 700
+    idx = _mk(1024, 8, 16, n)
+    X, g = _oracle_graph(oracle, idx, n, 8, 16)
+    rng = np.random.default_rng(21)
+    Q = X[rng.integers(0, n, nq)].copy()
+    want = [oracle.rad_traverse(g, X, Q[i], nts) for i in range(nq)]
+    t = DeviceTraversal(idx, Q, nts, log_pops=True, list_ring=ring)
+    assert t.kernel == "trav4_kernel" and t.slots == slots and t.list_ring == ring
+    assert t.run() == 0
+    st = t.stats()
+    assert set(st.status.tolist()) <= {1, 2}
+    for i in range(nq):
+        assert st.n_pops[i] == want[i].n_pops and st.n_nbr[i] == want[i].n_nbr and st.n_scored[i] == len(want[i].slots), i
+        nodes, lv = t.pop_log(i)                                            # (pop logs are kept per traversal)
+        assert np.array_equal(nodes, want[i].pop_nodes) and np.array_equal(lv, want[i].pop_levels), i
+    for i in range(nq - ring, nq):
+        s, a, o = t.results(i)
+        assert np.array_equal(s, want[i].slots) and np.array_equal(a, want[i].and_cnt) and np.array_equal(o, want[i].or_cnt), i
+    h = t.result_hashes(nq - ring, ring)
+    assert [int(x) for x in h] == [oracle.result_hash(w.slots, w.and_cnt, w.or_cnt) for w in want[nq - ring:]]
+    with pytest.raises(RadHipError):
+        t.results(nq - ring - 1)
+    with pytest.raises(RadHipError):
+        t.result_hashes(0, nq)
+    # a shorter batch on the same object (reset with fewer queries), then a full one again
+    Q2 = X[rng.integers(0, n, 30)].copy()
+    want2 = [oracle.rad_traverse(g, X, Q2[i], nts) for i in range(30)]
+    t.reset(Q2)
+    assert t.run() == 0
+    st2 = t.stats()
+    assert len(st2.n_pops) == 30 and [int(x) for x in st2.n_pops] == [w.n_pops for w in want2]
+    for i in range(max(0, 30 - ring), 30):
+        s, a, o = t.results(i)
+        assert np.array_equal(s, want2[i].slots), i
+    t.reset(Q)
+    assert t.run() == 0
+    assert [int(x) for x in t.stats().n_pops] == [w.n_pops for w in want]
+    t.close()
+    idx.close()

@@ -11,7 +11,7 @@ OUT=gpurun_out/prof_r04
 mkdir -p $OUT
 B="bench.py --no-cpu-baseline --no-kernel-legs --no-config-legs --secondary-expansion-add 0 --graph-cache /tmp/radhip_graph"
 echo "== kernel trace + stats" | tee -a $OUT/session.log
-timeout -k 10 700 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o bench -- python3 $B --steps 6 --warmup 1 > $OUT/bench_under_rocprof.json 2>> $OUT/session.log || echo "stats run failed" | tee -a $OUT/session.log
+timeout -k 10 700 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o bench -- python3 $B --steps 6 --warmup 6 > $OUT/bench_under_rocprof.json 2>> $OUT/session.log || echo "stats run failed" | tee -a $OUT/session.log
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
 head -8 $OUT/bench_kernel_stats.csv | tee -a $OUT/session.log
 rm -rf $OUT/stats

@@ -1039,8 +1039,13 @@ def main():
             if (pj.get("traverse_build_id") == _lib.traverse_build_id() and pj.get("n") == n and pj.get("nq") == args.nq and pj.get("n_to_score") == args.n_to_score
                     and pj.get("corpus_mode", 1) == args.corpus_mode and pj.get("table") == leg["table"] and pj.get("expansion_add", 64) == args.expansion_add):
                 rf = out["roofline"]
+                # the counters were taken on ONE launch of one batch; a launch of this run is a chain of steps: per-expansion counts,
+                # scaled by the expansions of a launch here
+                scale = (leg["pops"] / max(leg["launches"], 1)) / max(pj.get("expansions_per_launch") or 1.0, 1.0)
                 tr = pj.get("hbm_bytes_per_launch")
+                tr = tr * scale if tr else tr
                 rf["traffic"] = tr
+                rf["traffic_per_expansion_bytes"] = (pj.get("hbm_bytes_per_launch") or 0) / max(pj.get("expansions_per_launch") or 1.0, 1.0)
                 rf["traffic_source"] = "profiles/traffic_latest.json (rocprofv3 --pmc, separate passes, measured offline; every memory-side read request is a 128-B line, partial writes are 32-B requests: profiles/r04/probe_request_size.md)"
                 busy_per_launch = rf["kernel_busy_ms_per_launch"] * 1e-3
                 if tr:
@@ -1052,6 +1057,7 @@ def main():
                 rq, wq = pj.get("read_requests_128B"), (pj.get("write_requests") or {}).get("total")
                 w64 = (pj.get("write_requests") or {}).get("64B") or 0
                 if rq and wq:
+                    rq, wq, w64 = rq * scale, wq * scale, w64 * scale
                     rate = (rq + wq) / busy_per_launch / 1e9
                     rf["memory_requests"] = {
                         "reads_per_launch": rq, "writes_per_launch": wq, "writes_64B_per_launch": w64, "achieved_G_per_s": rate,

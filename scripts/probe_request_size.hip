@@ -137,7 +137,11 @@ int main(int argc, char **argv) {
     const double gib = argc > 1 ? atof(argv[1]) : 32.0;
     const uint32_t wpc = argc > 2 ? (uint32_t)atoi(argv[2]) : 16u;
     uint64_t lines = 1; while (lines * 2 * 128 <= (uint64_t)(gib * (1ull << 30))) lines *= 2;
-    uint8_t *buf; CK(hipMalloc(&buf, lines * 128)); CK(hipMemset(buf, 1, lines * 128));
+    const unsigned kind = argc > 3 ? (unsigned)atoi(argv[3]) : 0u;       // 0 plain hipMalloc, 1 fine-grained, 3 uncached (hipExtMallocWithFlags)
+    uint8_t *buf;
+    if (kind) CK(hipExtMallocWithFlags((void **)&buf, lines * 128, kind)); else CK(hipMalloc(&buf, lines * 128));
+    CK(hipMemset(buf, 1, lines * 128));
+    printf("allocation kind %u (%s)\n", kind, kind == 0 ? "hipMalloc" : kind == 1 ? "hipDeviceMallocFinegrained" : kind == 3 ? "hipDeviceMallocUncached" : "?");
     uint64_t *out; CK(hipMalloc(&out, 64));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const uint32_t blocks = 256 * wpc, iters = 1000;

@@ -262,7 +262,7 @@ def run_chained_leg(args, idx, batches, steps, warmup, barrier):
     acc = {"pops": 0, "evals": 0, "nbrs": 0, "k_ms": [], "iv": []}
 
     def launch(first_b, n_b, timed):
-        q = np.concatenate(batches[first_b:first_b + n_b]) if n_b > 1 else batches[first_b]
+        q = inputs[(first_b, n_b)]
         obj.reset(q)
         assert obj.run(0) == 0
         if timed:
@@ -273,6 +273,14 @@ def run_chained_leg(args, idx, batches, steps, warmup, barrier):
             return st
         return None
 
+    # the query matrix of every launch, laid out before the clock starts (the step = upload + arm + traverse + read the counters back)
+    inputs, b = {}, 0
+    for lo_b, n_all in ((0, warmup), (warmup, steps)):
+        b = lo_b
+        while b < lo_b + n_all:
+            c = min(chain, lo_b + n_all - b)
+            inputs[(b, c)] = np.ascontiguousarray(np.concatenate(batches[b:b + c]) if c > 1 else batches[b])
+            b += c
     b = 0
     while b < warmup:
         c = min(chain, warmup - b); launch(b, c, False); b += c

@@ -507,7 +507,6 @@ struct radhip_traversal {
     bool sharded = false; // the row-sharded form of trav4_kernel (shard.hip): stepped, never run()
     size_t gt_bytes = 0;
     uint64_t graph_gen = 0;   // generation of the index this state was sized for
-    std::vector<uint8_t> h_queries;   // host copy: the grouped table's overflow fallback re-arms the batch itself
     uint32_t ht_log2 = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0.0;
@@ -531,39 +530,54 @@ static uint32_t log2_ceil(uint64_t x) {
     return l;
 }
 
+// Arm the first `na` traversals on the device: a fresh header each (its popcount formed from the query row that is already
+// there), so that a chain of ten bench steps (655360 traversals) moves its 84 MB of queries to the device once and nothing else.
+__global__ __launch_bounds__(256) void trav_arm_kernel(TravHeader *hdr, const uint4 *queries, uint32_t row_vec, uint32_t na, uint64_t target) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= na) return;
+    const uint4 *q = queries + (size_t)i * row_vec;
+    uint32_t p = 0;
+    for (uint32_t w = 0; w < row_vec; ++w) { const uint4 v = q[w]; p += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+    TravHeader h = {};
+    h.qpop = p;
+    h.target = target;
+    h.frontier_key = RH_KEY_INF;
+    h.pivot = RH_KEY_INF;
+    h.dq = DQ_INIT;
+    h.mid_limit = RH_KEY_INF;
+    h.far_min = RH_KEY_INF;
+    h.dm = 1u << 12;
+    hdr[i] = h;
+}
+// the statistics of the first `na` traversals, packed for the host (56 bytes each instead of the whole header)
+__global__ __launch_bounds__(256) void trav_stats_kernel(const TravHeader *hdr, radhip_trav_stats_t *out, uint32_t na) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= na) return;
+    const TravHeader &h = hdr[i];
+    radhip_trav_stats_t o;
+    o.n_scored = h.n_scored; o.n_pops = h.n_pops; o.n_nbr = h.n_nbr; o.n_repivot = h.n_repivot; o.n_flush = h.n_flush;
+    o.status = h.status; o.n_remid = (int32_t)h.n_remid; o.n_upper = h.n_upper;
+    out[i] = o;
+}
+
+// queries == nullptr: the batch's queries are on the device already (the capacity fallbacks of run() re-arm the batch themselves)
 static int trav_upload_queries(radhip_traversal *t, const uint8_t *queries) {
     radhip_index *idx = t->idx;
     const uint32_t na = t->n_active;       // (the first n_active traversals of the object are armed)
-    if (queries != t->h_queries.data()) {   // host copy: the capacity fallbacks of run() re-arm the batch themselves
-        try { t->h_queries.assign(queries, queries + (size_t)na * idx->row_bytes); }
-        catch (...) { RH_FAIL(RADHIP_E_NOMEM, "out of host memory"); }
-    }
-    std::vector<uint8_t> padded((size_t)na * idx->row_stride, 0);
-    std::vector<TravHeader> hdr(na);
-    memset(hdr.data(), 0, hdr.size() * sizeof(TravHeader));
     t->P.nq = na;
-    for (uint32_t i = 0; i < na; ++i) {
-        memcpy(padded.data() + (size_t)i * idx->row_stride, queries + (size_t)i * idx->row_bytes, idx->row_bytes);
-        uint32_t p = 0;
-        {   // (a chain of ten bench steps is 655360 queries: eight bytes at a time)
-            const uint8_t *row = queries + (size_t)i * idx->row_bytes;
-            uint32_t b = 0;
-            for (; b + 8 <= idx->row_bytes; b += 8) { uint64_t w; memcpy(&w, row + b, 8); p += (uint32_t)__builtin_popcountll(w); }
-            for (; b < idx->row_bytes; ++b) p += (uint32_t)__builtin_popcount(row[b]);
-        }
-        hdr[i].qpop = p;
-        hdr[i].target = t->n_to_score;
-        hdr[i].frontier_key = RH_KEY_INF;
-        hdr[i].pivot = RH_KEY_INF;
-        hdr[i].dq = DQ_INIT;
-        hdr[i].mid_limit = RH_KEY_INF;
-        hdr[i].far_min = RH_KEY_INF;
-        hdr[i].dm = 1u << 12;
-    }
     if (t->in_flight) RH_FAIL(RADHIP_E_STATE, "the traversal object has a launch in flight: radhip_traversal_finish first");
     hipStream_t st = t->stream;
-    RH_HIP(hipMemcpyAsync(t->d_queries, padded.data(), padded.size(), hipMemcpyHostToDevice, st));
-    RH_HIP(hipMemcpyAsync(t->P.hdr, hdr.data(), (size_t)na * sizeof(TravHeader), hipMemcpyHostToDevice, st));
+    if (queries) {
+        if (idx->row_stride == idx->row_bytes) {
+            RH_HIP(hipMemcpyAsync(t->d_queries, queries, (size_t)na * idx->row_bytes, hipMemcpyHostToDevice, st));
+        } else {   // rows padded to the device's stride: the padding is zero
+            RH_HIP(hipMemsetAsync(t->d_queries, 0, (size_t)na * idx->row_stride, st));
+            RH_HIP(hipMemcpy2DAsync(t->d_queries, idx->row_stride, queries, idx->row_bytes, idx->row_bytes, na, hipMemcpyHostToDevice, st));
+        }
+    }
+    hipLaunchKernelGGL(trav_arm_kernel, dim3((na + 255u) / 256u), dim3(256), 0, st, t->P.hdr, (const uint4 *)t->d_queries,
+                       (uint32_t)(idx->row_stride / 16u), na, (uint64_t)t->n_to_score);
+    RH_HIP(hipGetLastError());
     if (t->P.slots) {
         // per-row epochs live on the device (a row bumps its own when it takes a traversal and clears its own tables when
         // they run out): re-arming a batch touches no table at all
@@ -982,7 +996,7 @@ static int trav_fall_back_to_hash(radhip_traversal *t) {
         t->fresh_tables = true;
         const double ms = t->kernel_ms;
         const uint64_t launches = t->launches;
-        RH_TRY(trav_upload_queries(t, t->h_queries.data()));
+        RH_TRY(trav_upload_queries(t, nullptr));
         t->kernel_ms = ms; t->launches = launches;
         return RADHIP_OK;
     }
@@ -1001,7 +1015,7 @@ static int trav_fall_back_to_hash(radhip_traversal *t) {
     t->fresh_tables = true;
     const double ms = t->kernel_ms;
     const uint64_t launches = t->launches;
-    RH_TRY(trav_upload_queries(t, t->h_queries.data()));
+    RH_TRY(trav_upload_queries(t, nullptr));
     t->kernel_ms = ms; t->launches = launches;   // the aborted launch stays on the clock
     return RADHIP_OK;
 }
@@ -1053,7 +1067,7 @@ static int trav_grow_upper(radhip_traversal *t) {
     // are put back afterwards
     std::vector<TravHeader> old(t->nq);
     RH_HIP(hipMemcpy(old.data(), P.hdr, t->hdr_bytes, hipMemcpyDeviceToHost));
-    RH_TRY(trav_upload_queries(t, t->h_queries.data()));
+    RH_TRY(trav_upload_queries(t, nullptr));
     {
         std::vector<TravHeader> hdr(t->nq);
         RH_HIP(hipMemcpy(hdr.data(), P.hdr, t->hdr_bytes, hipMemcpyDeviceToHost));
@@ -1194,15 +1208,17 @@ extern "C" int radhip_traversal_stats(const radhip_traversal_t *t, radhip_trav_s
     if (!t || !out) RH_FAIL(RADHIP_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(t->idx->mu);
     RH_HIP(hipSetDevice(t->idx->device));
-    std::vector<TravHeader> hdr(t->n_active);
-    RH_HIP(hipMemcpy(hdr.data(), t->P.hdr, (size_t)t->n_active * sizeof(TravHeader), hipMemcpyDeviceToHost));
     if (t->n_active < t->nq) memset(out + t->n_active, 0, (size_t)(t->nq - t->n_active) * sizeof *out);   // (not armed in this batch)
-    for (uint32_t i = 0; i < t->n_active; ++i) {
-        out[i].n_scored = hdr[i].n_scored; out[i].n_pops = hdr[i].n_pops; out[i].n_nbr = hdr[i].n_nbr;
-        out[i].n_repivot = hdr[i].n_repivot; out[i].n_flush = hdr[i].n_flush;
-        out[i].status = hdr[i].status; out[i].n_remid = (int32_t)hdr[i].n_remid;
-        out[i].n_upper = hdr[i].n_upper;
-    }
+    radhip_trav_stats_t *d_out = nullptr;
+    const size_t bytes = (size_t)t->n_active * sizeof *out;
+    hipError_t e = hipMalloc((void **)&d_out, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); RH_FAIL(e == hipErrorOutOfMemory ? RADHIP_E_NOMEM : RADHIP_E_HIP, "hipMalloc(%zu) for the statistics failed: %s", bytes, hipGetErrorString(e)); }
+    hipLaunchKernelGGL(trav_stats_kernel, dim3((t->n_active + 255u) / 256u), dim3(256), 0, t->stream, t->P.hdr, d_out, t->n_active);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) RH_FAIL(RADHIP_E_HIP, "reading the statistics failed: %s", hipGetErrorString(e));
     return RADHIP_OK;
 }
 

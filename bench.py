@@ -53,8 +53,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 RANDOM_LINE_PEAK_G = 38.2   # G random 128-B line reads per second at a 64 GiB footprint, measured (profiles/r03/latency_footprint.log)
 # request rates of the memory side by shape, 32 GiB footprint (scripts/probe_request_size.hip, profiles/r04/probe_request_size.md)
 READ_LINES_G = 44.0         # random 128-B line reads: 38.4 (16 B per lane, 64 lines per instruction) .. 48.5 (<= 32 lines per instruction)
-PARTIAL_WRITES_G = 21.9     # random writes of 4 .. 32 B (one 32-B request each)
-FULL_WRITES_G = 49.5        # random full 64-B writes
+PARTIAL_WRITES_G = 21.9     # random writes of 4 .. 32 B (one 32-B request each) into lines that are NOT in the L2
+FULL_WRITES_G = 49.5        # random full 64-B writes; a 4-B store into a line a read has just fetched costs the same (mix_store4_probed_line)
 METRIC = "neighbor-expansions/sec (1024-bit Tanimoto) + HBM GB/s vs roofline"
 
 
@@ -81,7 +81,7 @@ def parse_args():
                     help="N = 1: a second, shorter leg on a graph built with this expansion_add (0 = skip)")
     ap.add_argument("--graph-cache", default="", help="profiling sessions: .npz the built graph is saved to / loaded from, so that every "
                                                        "rocprofv3 pass does not build it again (the graph is the same; only setup time changes)")
-    ap.add_argument("--chain", type=int, default=10,
+    ap.add_argument("--chain", type=int, default=20,
                     help="steps (batches) chained into ONE launch of the traversal kernel: a launch ends with its longest traversals running "
                          "alone (~150 ms whatever its size), so the tail is paid once per chain (0 = the two-object pipeline of overlapped launches)")
     ap.add_argument("--no-overlap", action="store_true", help="one traversal object, one launch after the other (A/B against the two-stream pipeline)")
@@ -1060,8 +1060,10 @@ def main():
                     rf["hbm_real_gbs"] = tr / busy_per_launch / 1e9
                 # The ceiling this kernel really sits under: memory-side REQUESTS.  scripts/probe_request_size.hip (profiles/r04):
                 # an MI355X serves 38-49 G random 128-B line reads per second over a 32 GiB footprint (38 when a 16-B-per-lane
-                # load touches 64 lines, 49 when it touches 32 or fewer), 49 G full 64-B writes per second, but only 21.9 G
-                # writes of 32 B or less per second — a table entry store costs 2.2 line reads.
+                # load touches 64 lines, 49 when it touches 32 or fewer), 49 G full 64-B writes per second, and 21.9 G writes of
+                # 32 B or less per second into lines that are not in the L2 — but a 4-B store into the line a probe of the same
+                # round has fetched (the kernel's table entry store) goes at the 64-B rate: the expansion-shaped mix runs at
+                # 2.12 G rounds/s with its stores into probed lines or as whole sectors, 1.82 G/s with them elsewhere.
                 rq, wq = pj.get("read_requests_128B"), (pj.get("write_requests") or {}).get("total")
                 w64 = (pj.get("write_requests") or {}).get("64B") or 0
                 if rq and wq:
@@ -1071,13 +1073,16 @@ def main():
                         "reads_per_launch": rq, "writes_per_launch": wq, "writes_64B_per_launch": w64, "achieved_G_per_s": rate,
                         "device_random_line_reads_G_per_s": RANDOM_LINE_PEAK_G, "frac": rate / RANDOM_LINE_PEAK_G}
                     # what the SAME request mix could reach if nothing but the memory system's request rates bound it
-                    t_model = rq / (READ_LINES_G * 1e9) + (wq - w64) / (PARTIAL_WRITES_G * 1e9) + w64 / (FULL_WRITES_G * 1e9)
+                    t_model = rq / (READ_LINES_G * 1e9) + wq / (FULL_WRITES_G * 1e9)
+                    t_cold = rq / (READ_LINES_G * 1e9) + (wq - w64) / (PARTIAL_WRITES_G * 1e9) + w64 / (FULL_WRITES_G * 1e9)
                     alg = rf["algorithmic_bytes_per_launch"]
                     rf["attainable"] = {
                         "by_request_count_GBs": alg / ((rq + wq) / (RANDOM_LINE_PEAK_G * 1e9)) / 1e9,
                         "by_request_cost_model_GBs": alg / t_model / 1e9,
-                        "model": f"time >= reads / {READ_LINES_G} G/s + writes(<= 32 B) / {PARTIAL_WRITES_G} G/s + writes(64 B) / {FULL_WRITES_G} G/s "
+                        "model": f"time >= reads / {READ_LINES_G} G/s + writes / {FULL_WRITES_G} G/s: the kernel's writes of <= 32 B are table entries "
+                                 "stored into the line their probe has just fetched, which cost what a 64-B write costs "
                                  "(rates measured by scripts/probe_request_size.hip on this device class, 32 GiB footprint)",
+                        "if_small_writes_missed_the_L2_GBs": alg / t_cold / 1e9,
                         "achieved_over_model": rf["achieved"] / (alg / t_model / 1e9)}
         except Exception:
             pass

@@ -708,14 +708,20 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint4 *__restrict__ fp,
 template <int LPR>
 static int launch_scan(radhip_index *idx, int nq, uint64_t first, uint64_t count, const uint4 *dq,
                        const uint32_t *dqpop, uint32_t *da, uint32_t *dorr) {
-    uint64_t groups = (count + 255) / 256;   // 4 waves x 64-row tiles per block pass
-    uint32_t grid = (uint32_t)std::min<uint64_t>(groups, 256ull * 8ull);
-    if (grid == 0) grid = 1;
+    // the wavefronts stride over the tiles: the grid is what the device holds resident at once for this instantiation (2 blocks
+    // per CU at 8 queries per pass of 1024-bit rows, 227 VGPRs; 3 at 4 queries: a fixed 8 per CU would leave a ragged last round)
+    const uint64_t groups = (count + 255) / 256;   // 4 waves x 64-row tiles per block pass
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, idx->device);
+    uint32_t grid = 1;
 #define RH_SCAN_CASE(NQV)                                                                       \
-    case NQV:                                                                                   \
+    case NQV: {                                                                                 \
+        int nb = 0;                                                                             \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_kernel<LPR, NQV>, 256, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; } \
+        grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(groups, (uint64_t)n_cu * (uint64_t)nb)); \
         hipLaunchKernelGGL((scan_kernel<LPR, NQV>), dim3(grid), dim3(256), 0, idx->stream, idx->d_fp, \
                            first, count, dq, dqpop, da, dorr);                                  \
-        break;
+        break; }
     switch (nq) {
         RH_SCAN_CASE(1) RH_SCAN_CASE(2) RH_SCAN_CASE(3) RH_SCAN_CASE(4)
         RH_SCAN_CASE(5) RH_SCAN_CASE(6) RH_SCAN_CASE(7) RH_SCAN_CASE(8)

@@ -55,8 +55,38 @@ __device__ __forceinline__ void tk_append(unsigned long long *buf, uint32_t &cnt
     }
 }
 
+// one row per lane (and-counts against the NQ queries, its own popcount): offer it to the NQ candidate buffers of the wavefront
+template <int NQ>
+__device__ __forceinline__ void tk_offer(unsigned long long *buf, uint32_t C, uint32_t k, uint32_t lane, unsigned long long lt_mask,
+                                         bool in_range, uint32_t slot, uint32_t rp, const uint32_t (&a)[NQ], const uint32_t (&qp)[NQ],
+                                         uint32_t (&cnt)[NQ], unsigned long long (&thr)[NQ]) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        if (cnt[i] + 64u > C) cnt[i] = tk_compact(buf + (size_t)i * C, cnt[i], C, k, lane, thr[i]);
+        const uint32_t o = qp[i] + rp - a[i];
+        // cheap exact pre-filter: floor(x * 2^23 / o) <= T  <=>  x * 2^23 < (T + 1) * o; the quotient
+        // itself (a division) is computed only for the few rows that can enter the buffer
+        const unsigned long long tq1 = (thr[i] >> 32) + 1ull;
+        bool pass = in_range && (((unsigned long long)(o - a[i]) << 23) < tq1 * o || o == 0u);
+        unsigned long long key = TK_INF;
+        if (__ballot(pass)) {
+            if (pass) {
+                key = ((unsigned long long)rh_q24_dev(a[i], o) << 32) | slot;
+                pass = key < thr[i];
+            }
+            tk_append(buf + (size_t)i * C, cnt[i], pass, key, lt_mask);
+        }
+    }
+}
+
+// (experiment knob: -DTK_WAVES_PER_EU=4 caps the scan at 128 VGPRs — four wavefronts per SIMD at the price of spills)
+#ifdef TK_WAVES_PER_EU
+#define TK_OCC_ATTR __attribute__((amdgpu_waves_per_eu(TK_WAVES_PER_EU, TK_WAVES_PER_EU)))
+#else
+#define TK_OCC_ATTR
+#endif
 template <int LPR, int NQ>
-__global__ __launch_bounds__(256) void topk_scan_kernel(const uint4 *__restrict__ fp, uint64_t first, uint64_t count,
+__global__ __launch_bounds__(256) TK_OCC_ATTR void topk_scan_kernel(const uint4 *__restrict__ fp, uint64_t first, uint64_t count,
                                                         const uint4 *__restrict__ queries, const uint32_t *__restrict__ qpop,
                                                         uint32_t k, uint32_t C, unsigned long long *__restrict__ cand) {
     extern __shared__ unsigned long long tk_smem[];   // [4 wavefronts][NQ][C]
@@ -119,23 +149,108 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const uint4 *__restrict_
             }
         }
         const uint64_t r = r0 + (uint64_t)chunk * RPL + grp;   // the row this lane kept
+        tk_offer<NQ>(buf, C, k, lane, lt_mask, r < count, (uint32_t)(first + r), keep_rp, keep_a, qp, cnt, thr);
+    }
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            if (cnt[i] + 64u > C) cnt[i] = tk_compact(buf + (size_t)i * C, cnt[i], C, k, lane, thr[i]);
-            const uint32_t o = qp[i] + keep_rp - keep_a[i];
-            // cheap exact pre-filter: floor(x * 2^23 / o) <= T  <=>  x * 2^23 < (T + 1) * o; the quotient
-            // itself (a division) is computed only for the few rows that can enter the buffer
-            const unsigned long long tq1 = (thr[i] >> 32) + 1ull;
-            bool pass = r < count && (((unsigned long long)(o - keep_a[i]) << 23) < tq1 * o || o == 0u);
-            unsigned long long key = TK_INF;
-            if (__ballot(pass)) {
-                if (pass) {
-                    key = ((unsigned long long)rh_q24_dev(keep_a[i], o) << 32) | (uint32_t)(first + r);
-                    pass = key < thr[i];
-                }
-                tk_append(buf + (size_t)i * C, cnt[i], pass, key, lt_mask);
+    for (int i = 0; i < NQ; ++i) {
+        const uint32_t kept = tk_compact(buf + (size_t)i * C, cnt[i], C, k, lane, thr[i]);
+        unsigned long long *dst = cand + ((uint64_t)i * n_waves + wave) * k;
+        for (uint32_t j = lane; j < k; j += 64) dst[j] = j < kept ? buf[(size_t)i * C + j] : TK_INF;
+    }
+}
+
+// 1024-bit rows, ONE ROW PER LANE (round 4).  The kernel above is bound by its instruction stream, not by the memory (1200
+// instructions per tile of 64 rows x 8 queries = 3.0 ms of VALU issue for a 100M-row pass that HBM serves in 2.3 ms): a row lies
+// across eight lanes, so every count goes through a transpose-and-sum (252 instructions per tile) and every lane keeps its own
+// chunk of the eight queries in registers.  Here a wavefront loads its tile with the same coalesced 16-B-per-lane loads, turns it
+// over through LDS (rows 144 B apart: the 16-B reads of 16 lanes cover all 64 banks) and each lane counts a whole row — the
+// queries are the same for every lane, so they are scalar operands (s_load), and nothing crosses lanes.  The next tile's loads
+// are in flight while this one is counted.
+// popcount(x) + acc in ONE instruction (the compiler prefers trees of v_add3 over the accumulating form)
+__device__ __forceinline__ uint32_t tk_bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+}
+typedef const uint32_t __attribute__((address_space(4))) *tk_cptr;
+#define TK_TR_VEC (32 * 9)       // uint4 per wavefront: 32 rows (half a tile) of 8 chunks + 1 of padding
+#define TK_ROWS_WAVES 2          // wavefronts per block: 2 x (candidate buffers + 9 KB tile) stays under 64 KB of dynamic LDS for every k
+template <int NQ>
+__global__ __launch_bounds__(64 * TK_ROWS_WAVES) void topk_rows_kernel(const uint4 *__restrict__ fp, uint64_t first, uint64_t count,
+                                                        const uint32_t *__restrict__ qd /* [NQ][32] */, const uint32_t *__restrict__ qpop,
+                                                        uint32_t k, uint32_t C, unsigned long long *__restrict__ cand) {
+    extern __shared__ unsigned long long tk_smem[];   // [TK_ROWS_WAVES wavefronts][NQ][C] keys, then [TK_ROWS_WAVES][TK_TR_VEC] uint4
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t chunk = lane & 7u, grp = lane >> 3;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned long long *buf = tk_smem + (size_t)wv * NQ * C;
+    uint4 *tr = reinterpret_cast<uint4 *>(tk_smem + (size_t)TK_ROWS_WAVES * NQ * C) + (size_t)wv * TK_TR_VEC;
+    uint32_t qp[NQ], cnt[NQ];
+    unsigned long long thr[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) { qp[i] = qpop[i]; cnt[i] = 0; thr[i] = TK_INF; }
+    const uint64_t n_tiles = (count + 63) / 64;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    uint4 nv[8];
+    auto load_tile = [&](uint64_t tile) {
+        const uint64_t r0 = tile * 64;
+        if (r0 + 64 <= count) {   // (wave-uniform: every tile but the last)
+            const uint4 *base = fp + (first + r0 + grp) * 8 + chunk;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) nv[u] = base[u * 64];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint64_t r = r0 + (uint64_t)u * 8 + grp;
+                nv[u] = make_uint4(0, 0, 0, 0);
+                if (r < count) nv[u] = fp[(first + r) * 8 + chunk];
             }
         }
+    };
+    uint64_t tile = wave;
+    if (tile < n_tiles) load_tile(tile);
+    for (; tile < n_tiles; tile += n_waves) {
+        // the tile is turned over in two halves of 32 rows (4.6 KB of LDS per wavefront instead of 9.2: three wavefronts per SIMD
+        // fit beside the candidate buffers): rows 0..31 go to lanes 0..31, rows 32..63 to lanes 32..63
+        uint4 v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tr[(u * 8 + grp) * 9 + chunk] = nv[h * 4 + u];
+            RH_WAVE_SYNC();
+            if ((int)(lane >> 5) == h) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = tr[(lane & 31u) * 9 + c];
+            }
+            RH_WAVE_SYNC();   // (the half tile is written again right away)
+        }
+        if (tile + n_waves < n_tiles) load_tile(tile + n_waves);
+        uint32_t rp = 0, a[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) a[i] = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) rp = tk_bcnt_acc(v[c].x, tk_bcnt_acc(v[c].y, tk_bcnt_acc(v[c].z, tk_bcnt_acc(v[c].w, rp))));
+#pragma unroll
+        for (int cb = 0; cb < 8; cb += 4) {
+            // the same address in every lane: scalar loads from the constant address space (64 B = four chunks of a query at a
+            // time) — behind an offset the compiler cannot see through (0, made wave-uniform again), or it keeps all 256 query
+            // words of the pass in scalar registers across the tile loop and spills them into lanes (314 v_readlane per tile)
+            uint32_t off = 0;
+            asm volatile("" : "+v"(off));
+            const tk_cptr qc = (tk_cptr)(uintptr_t)qd + __builtin_amdgcn_readfirstlane(off) + cb * 4;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const tk_cptr q = qc + i * 32;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const uint4 &x = v[cb + cc];
+                    a[i] = tk_bcnt_acc(x.x & q[cc * 4], tk_bcnt_acc(x.y & q[cc * 4 + 1], tk_bcnt_acc(x.z & q[cc * 4 + 2], tk_bcnt_acc(x.w & q[cc * 4 + 3], a[i]))));
+                }
+            }
+        }
+        const uint64_t r = tile * 64 + lane;
+        tk_offer<NQ>(buf, C, k, lane, lt_mask, r < count, (uint32_t)(first + r), rp, a, qp, cnt, thr);
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -195,14 +310,38 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const uint4 *__restrict_
 
 static uint32_t tk_pow2ceil(uint32_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p; }
 
+// The scan's wavefronts stride over the tiles, so its grid is exactly what the device holds resident at once: at 8 queries per
+// pass the kernel takes 160 VGPRs (three blocks per CU), and a fourth block per CU would run alone on a mostly idle chip
+// after the others (round 4: 3.36 ms -> see profiles/r04/README.md for the 100M-row pass).
+template <int LPR, int NQV>
+static uint32_t tk_resident_grid(uint32_t grid_cap, int n_cu, size_t lds) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, topk_scan_kernel<LPR, NQV>, 256, lds) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid_cap, (uint64_t)n_cu * (uint64_t)nb));
+}
+
 template <int LPR>
 static int tk_run_pass(radhip_index *idx, int nqp, uint64_t first, uint64_t count, const uint4 *dq, const uint32_t *dpop,
-                       uint32_t k, uint32_t C, uint32_t grid, unsigned long long *dcand, uint32_t *ds, uint32_t *da,
+                       uint32_t k, uint32_t C, uint32_t grid_cap, int n_cu, unsigned long long *dcand, uint32_t *ds, uint32_t *da,
                        uint32_t *dorr, uint32_t *dc) {
-    const size_t lds_scan = (size_t)4 * nqp * C * 8;
-    const uint64_t n_waves = (uint64_t)grid * 4;
+    size_t lds_scan = (size_t)4 * nqp * C * 8;
+    uint32_t grid = grid_cap, waves_per_block = 4;
+    // 1024-bit rows: one row per lane (topk_rows_kernel; RADHIP_TOPK_ROWS=0 keeps the row-across-eight-lanes kernel: the A/B of
+    // profiles/r04)
+    static const bool rows_ok = []() { const char *e = getenv("RADHIP_TOPK_ROWS"); return !(e && e[0] == '0'); }();
+    const bool rows = LPR == 8 && rows_ok;
+    if (rows) { waves_per_block = TK_ROWS_WAVES; lds_scan = (size_t)TK_ROWS_WAVES * ((size_t)nqp * C * 8 + (size_t)TK_TR_VEC * 16); }
 #define TK_CASE(NQV)                                                                                   \
     case NQV:                                                                                          \
+        if (rows) {                                                                                    \
+            int nb = 0;                                                                                \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, topk_rows_kernel<NQV>, 64 * TK_ROWS_WAVES, lds_scan) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; } \
+            grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid_cap, (uint64_t)n_cu * (uint64_t)nb)); \
+            hipLaunchKernelGGL((topk_rows_kernel<NQV>), dim3(grid), dim3(64 * TK_ROWS_WAVES), lds_scan, idx->stream,  \
+                               idx->d_fp, first, count, reinterpret_cast<const uint32_t *>(dq), dpop, k, C, dcand); \
+            break;                                                                                     \
+        }                                                                                              \
+        grid = tk_resident_grid<LPR, NQV>(grid_cap, n_cu, lds_scan);                                   \
         hipLaunchKernelGGL((topk_scan_kernel<LPR, NQV>), dim3(grid), dim3(256), lds_scan, idx->stream, \
                            idx->d_fp, first, count, dq, dpop, k, C, dcand);                            \
         break;
@@ -212,6 +351,7 @@ static int tk_run_pass(radhip_index *idx, int nqp, uint64_t first, uint64_t coun
     }
 #undef TK_CASE
     RH_HIP(hipGetLastError());
+    const uint64_t n_waves = (uint64_t)grid * waves_per_block;
     hipLaunchKernelGGL((topk_merge_kernel<LPR>), dim3(nqp), dim3(64), (size_t)C * 8, idx->stream, idx->d_fp, dq, dpop, k, C,
                        dcand, n_waves * k, ds, da, dorr, dc);
     RH_HIP(hipGetLastError());
@@ -240,7 +380,8 @@ extern "C" int radhip_tanimoto_topk(radhip_index_t *idx, const uint8_t *queries,
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, idx->device);
     const uint64_t tiles = (count + 63) / 64;
-    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((tiles + 3) / 4, (uint64_t)n_cu * 4));
+    // (the most blocks any instantiation holds resident: tk_resident_grid takes what its own occupancy allows)
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((tiles + 3) / 4, (uint64_t)n_cu * 8));
     std::vector<uint8_t> padded;
     std::vector<uint32_t> pop;
     rh_stage_queries(idx, queries, nq, padded, pop);
@@ -266,11 +407,11 @@ extern "C" int radhip_tanimoto_topk(radhip_index_t *idx, const uint8_t *queries,
         const int nqp = (int)std::min<uint32_t>(pass, nq - q0);
         const uint4 *dqk = dq + (size_t)q0 * idx->lpr;
         switch (idx->lpr) {
-            case 1: rc = tk_run_pass<1>(idx, nqp, first, count, dqk, dpop + q0, k, C, grid, dcand, ds, da, dorr, dc); break;
-            case 2: rc = tk_run_pass<2>(idx, nqp, first, count, dqk, dpop + q0, k, C, grid, dcand, ds, da, dorr, dc); break;
-            case 4: rc = tk_run_pass<4>(idx, nqp, first, count, dqk, dpop + q0, k, C, grid, dcand, ds, da, dorr, dc); break;
-            case 8: rc = tk_run_pass<8>(idx, nqp, first, count, dqk, dpop + q0, k, C, grid, dcand, ds, da, dorr, dc); break;
-            default: rc = tk_run_pass<16>(idx, nqp, first, count, dqk, dpop + q0, k, C, grid, dcand, ds, da, dorr, dc); break;
+            case 1: rc = tk_run_pass<1>(idx, nqp, first, count, dqk, dpop + q0, k, C, grid, n_cu, dcand, ds, da, dorr, dc); break;
+            case 2: rc = tk_run_pass<2>(idx, nqp, first, count, dqk, dpop + q0, k, C, grid, n_cu, dcand, ds, da, dorr, dc); break;
+            case 4: rc = tk_run_pass<4>(idx, nqp, first, count, dqk, dpop + q0, k, C, grid, n_cu, dcand, ds, da, dorr, dc); break;
+            case 8: rc = tk_run_pass<8>(idx, nqp, first, count, dqk, dpop + q0, k, C, grid, n_cu, dcand, ds, da, dorr, dc); break;
+            default: rc = tk_run_pass<16>(idx, nqp, first, count, dqk, dpop + q0, k, C, grid, n_cu, dcand, ds, da, dorr, dc); break;
         }
         if (rc != RADHIP_OK) break;
         TK_G(hipMemcpyAsync(out_slots + (size_t)q0 * k, ds, (size_t)nqp * k * 4, hipMemcpyDeviceToHost, idx->stream));

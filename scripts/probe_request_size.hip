@@ -98,6 +98,45 @@ __global__ __launch_bounds__(64) void mix_like_an_expansion(uint8_t *buf, uint64
     if (acc == 0x12345678u) out[1] = acc;
 }
 
+// The same mix with the four entry stores (a) into the line a probe of this round has just fetched, as in the kernel, and / or
+// (b) as FULL 64-B sectors (four lanes x 16 B: the cheap kind of write) instead of 4-B partial writes: what would a table whose
+// entry store rewrites a whole sector buy?  (The sector's other bytes would come from a probe widened to 64 B: the same request.)
+template <bool W64, bool SAME_LINE>
+__device__ __forceinline__ void mix_body(uint8_t *buf, uint64_t lines, uint32_t iters, uint64_t *out) {
+    const uint32_t lane = threadIdx.x, row = lane >> 4, gl = lane & 15u;
+    uint64_t s = mix(((uint64_t)blockIdx.x << 8 | row) + 0x77ull);
+    uint32_t acc = 0;
+    for (uint32_t it = 0; it < iters; ++it) {
+        s = mix(s + 0x9E3779B97F4A7C15ull);
+        const uint32_t a = *reinterpret_cast<const uint32_t *>(buf + (s & (lines - 1)) * 128 + gl * 4);
+        uint64_t t = mix(s ^ ((uint64_t)gl << 40) ^ (uint64_t)(a == 0xDEADBEEFu));
+        uint4 pv = make_uint4(0, 0, 0, 0);
+        if (gl < 10) pv = *reinterpret_cast<const uint4 *>(buf + (t & (lines - 1)) * 128 + (t >> 61) * 16);
+        acc += pv.x;
+        uint4 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint64_t r = mix(s + (uint64_t)u * 2 + (gl >> 3) + (uint64_t)(acc == 0xDEADBEEFu));
+            v[u] = *reinterpret_cast<const uint4 *>(buf + (r & (lines - 1)) * 128 + (gl & 7u) * 16);
+        }
+        acc += v[0].x + v[1].y;
+        if constexpr (W64) {
+            const uint32_t src = (lane & ~15u) + (gl >> 2);                 // lanes 4g .. 4g+3 write the sector lane g probed
+            const uint64_t tg = SAME_LINE ? __shfl(t, src) : mix(__shfl(t, src) + 1);
+            *reinterpret_cast<uint4 *>(buf + (tg & (lines - 1)) * 128 + (tg >> 63) * 64 + (gl & 3u) * 16) = make_uint4(acc, it, lane, 7u);
+        } else {
+            const uint64_t tg = SAME_LINE ? t : mix(t + acc);
+            if (gl < 4) *reinterpret_cast<uint32_t *>(buf + (tg & (lines - 1)) * 128 + (tg >> 61) * 16 + 4) = acc;
+        }
+        s ^= (uint64_t)(acc == 0xDEADBEEFu);
+    }
+    if (acc == 0x12345678u) out[1] = acc;
+}
+__global__ __launch_bounds__(64) void mix_store4_other_line(uint8_t *b, uint64_t l, uint32_t it, uint64_t *o) { mix_body<false, false>(b, l, it, o); }
+__global__ __launch_bounds__(64) void mix_store4_probed_line(uint8_t *b, uint64_t l, uint32_t it, uint64_t *o) { mix_body<false, true>(b, l, it, o); }
+__global__ __launch_bounds__(64) void mix_store64_other_line(uint8_t *b, uint64_t l, uint32_t it, uint64_t *o) { mix_body<true, false>(b, l, it, o); }
+__global__ __launch_bounds__(64) void mix_store64_probed_line(uint8_t *b, uint64_t l, uint32_t it, uint64_t *o) { mix_body<true, true>(b, l, it, o); }
+
 // What a new table entry costs: a group of 4 lanes works on one random line per step.  Lane 0 probes 16 B of it (the bucket
 // probe); then either lane 0 stores 4 B into it (today's entry store: a partial write) or all four lanes read the 64-B half
 // line back (an L2 hit: the probe has just fetched the line) and store the whole 64 B (REWRITE = true).
@@ -181,5 +220,16 @@ int main(int argc, char **argv) {
         printf("%-22s %8.3f ms  %14.0f expansion-shaped rounds (1 half line + 10 probes + 4 rows + 4 entry stores = 19 requests)  %7.2f G rounds/s = %7.2f G requests/s\n",
                "mix_like_an_expansion", ms, rows, rows / (ms * 1e-3) / 1e9, rows * 19 / (ms * 1e-3) / 1e9);
     }
+#define RUNMIX(K)                                                                                                          \
+    do {                                                                                                                   \
+        K<<<blocks, 64>>>(buf, lines, iters, out); CK(hipDeviceSynchronize());                                             \
+        CK(hipEventRecord(e0)); K<<<blocks, 64>>>(buf, lines, iters, out); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); \
+        CK(hipEventElapsedTime(&ms, e0, e1));                                                                              \
+        printf("%-26s %8.3f ms  %7.3f G rounds/s\n", #K, ms, (double)blocks * 4 * iters / (ms * 1e-3) / 1e9); fflush(stdout);  \
+    } while (0)
+    RUNMIX(mix_store4_other_line);
+    RUNMIX(mix_store4_probed_line);
+    RUNMIX(mix_store64_other_line);
+    RUNMIX(mix_store64_probed_line);
     return 0;
 }

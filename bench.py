@@ -1087,6 +1087,22 @@ def main():
         except Exception:
             pass
 
+    armed = False
+    if world > 1 and rank == 0 and args.mode == "replicas":
+        # The measured leg is done.  The side legs below run paths no single-GPU box can rehearse (reads over xGMI, multi-rank
+        # RCCL): should a GPU fault end this process inside the HIP runtime, or the launcher end it because another rank died,
+        # the library writes this line instead — the replicas result and what happened (include/rad_hip.h radhip_arm_last_words)
+        try:
+            from rad_amd import _lib as _lw
+            last = dict(out)
+            last["config"] = dict(config, parallelism="replicas (--mode replicas): every GPU holds the whole corpus and graph, the query batch is split, no collective")
+            why = {"error": "the process was ended by a signal inside the side legs (a GPU fault, or the launcher's SIGTERM after another rank died): not measured"}
+            last["peer_mapped"], last["sharded"] = why, why
+            last["replicas"] = {"value": value_replicas, "unit": "expansions/s"}
+            armed = _lw.lib().radhip_arm_last_words(json.dumps(last).encode()) == 0
+        except Exception:   # noqa: BLE001 - a guard, not a requirement
+            armed = False
+
     if world > 1 and not args.no_peer_leg:
         # side leg 1: the peer-mapped corpus (rows sharded, single-GPU kernel over xGMI reads); this rank's whole-corpus index is
         # still here and serves as the parity reference
@@ -1165,6 +1181,10 @@ def main():
         else:
             config["parallelism"] = "replicas (--mode replicas): " + replicas["partitioning"]
         out["sharded"], out["replicas"] = sharded, replicas
+
+    if armed:
+        from rad_amd import _lib as _lw
+        _lw.lib().radhip_arm_last_words(None)
 
     if rank != 0:
         grp.barrier()

@@ -58,6 +58,11 @@ const char *radhip_build_id(void);
 /* the same for the traversal kernels alone (traverse.hip, traverse4.inc, common.h): the key of measured counters kept beside the code */
 const char *radhip_traverse_build_id(void);
 int radhip_device_count(int *out_count);
+/* Keep a copy of `line`; while armed, SIGABRT / SIGSEGV / SIGBUS / SIGTERM write it to stdout and end the process with status 0
+ * (a multi-GPU bench whose measured leg is done arms this before side legs that a GPU fault or a launcher's SIGTERM could end:
+ * the line the caller composed says so).  NULL disarms and restores the previous handlers.  The reference's counterpart of surviving a dead worker is the re-queueing of its stale work
+ * assignment (rad/coordination_service.py:554-574); a benchmark process has nobody to re-queue for it. */
+int radhip_arm_last_words(const char *line);
 
 /* ---- index: corpus + layered adjacency resident in HBM ----------------- */
 typedef struct radhip_index radhip_index_t;

@@ -63,6 +63,7 @@ SIGNATURES = {
     "radhip_backend_name": (C.c_char_p, []),
     "radhip_abi_version": (C.c_int, []),
     "radhip_build_id": (C.c_char_p, []),
+    "radhip_arm_last_words": (C.c_int, [C.c_char_p]),
     "radhip_traverse_build_id": (C.c_char_p, []),
     "radhip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "radhip_index_create": (C.c_int, [_U32, _U32, _U32, _U32, C.c_int, C.POINTER(_P)]),

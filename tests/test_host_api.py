@@ -450,3 +450,34 @@ def test_http_front_serves_the_reference_json_shapes(tmp_path):
     m = c.post("/neighbors-many", headers=hdr, json={"pairs": [[5, 0], [6, 0]]}).json()
     assert [x["neighbors"] for x in m["results"]] == [c.get("/neighbors/5/0", headers=hdr).json()["neighbors"],
                                                       c.get("/neighbors/6/0", headers=hdr).json()["neighbors"]]
+
+
+def test_last_words_survive_a_fatal_signal():
+    """radhip_arm_last_words: while armed, SIGABRT (what the HIP runtime raises on a GPU fault) and SIGTERM (what a launcher sends the
+    surviving ranks) write the kept line to stdout and end the process with status 0; disarmed, the signal acts as before.
+    bench.py --gpus N arms it with the measured replicas line before its side legs."""
+    import subprocess
+    import sys
+    import textwrap
+    prog = textwrap.dedent('''
+        import os, signal, sys
+        sys.path.insert(0, %r)
+        from rad_amd import _lib
+        L = _lib.lib()
+        how = sys.argv[1]
+        assert L.radhip_arm_last_words(b'{"value": 1.5, "side": {"error": "ended by a signal"}}') == 0
+        if how == "disarm":
+            assert L.radhip_arm_last_words(None) == 0
+        print("not the line", file=sys.stderr)
+        if how == "term":
+            os.kill(os.getpid(), signal.SIGTERM)
+        else:
+            os.abort()
+    ''') % ROOT
+    for how, rc_ok in (("abort", True), ("term", True), ("disarm", False)):
+        r = subprocess.run([sys.executable, "-c", prog, how], capture_output=True, text=True, timeout=120)
+        if rc_ok:
+            assert r.returncode == 0, (how, r.returncode, r.stderr[-300:])
+            assert r.stdout == '{"value": 1.5, "side": {"error": "ended by a signal"}}\n'
+        else:
+            assert r.returncode != 0 and r.stdout == ""

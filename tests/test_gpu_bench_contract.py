@@ -109,3 +109,20 @@ def test_bench_two_ranks_from_a_bare_invocation(gpu):
     done, total = pm["parity_vs_whole_corpus_index"].split("/")
     assert done == total and int(total) >= 2 * 256 and pm["value"] > 0 and pm["rows_per_shard"] % 16384 == 0
     assert len(pm["index_bytes_per_rank"]) == 2 and pm["remote_share_of_row_reads"] == 0.5
+
+
+def test_bench_four_ranks_on_one_device(gpu):
+    """world 4 rehearsed on one GPU (four rank processes): the replicas line, the sharded leg (host-staged exchange) and the
+    peer-mapped leg (four dmabuf descriptors crossing a Unix socket; three quarters of the row reads are other ranks' rows),
+    each parity-gated; the measured line was armed as the process's last words while the side legs ran and disarmed after."""
+    j = _run("--gpus", "4", "--steps", "2", "--warmup", "1", "--rows", "400000", "--nq", "512", "--n-to-score", "1500",
+             "--sharded-nq", "64", "--exchange", "host", "--single-device")
+    _contract(j, 4, 2)
+    assert j["value"] == j["replicas"]["value"] > 0
+    done, total = j["sharded"]["parity_vs_single_gpu"].split("/")
+    assert done == total and int(total) >= 4 * 64
+    pm = j["peer_mapped"]
+    assert pm.get("error") is None, pm
+    done, total = pm["parity_vs_whole_corpus_index"].split("/")
+    assert done == total and int(total) >= 4 * 256 and pm["remote_share_of_row_reads"] == 0.75
+    assert len(pm["index_bytes_per_rank"]) == 4

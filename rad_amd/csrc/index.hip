@@ -1,6 +1,7 @@
 // index.hip — index object (corpus + layered adjacency in HBM), synthetic
 // generators, K1 scan and K2 gather Tanimoto kernels.  gfx950 only.
 #include "common.h"
+#include "rows_tile.h"
 
 #include <algorithm>
 #include <new>
@@ -705,6 +706,43 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint4 *__restrict__ fp,
     }
 }
 
+// K1 on 1024-bit rows with ONE ROW PER LANE (rows_tile.h rh_rows_*): used from 5 queries per pass on, where the kernel above is
+// bound by its instruction stream (1090 VALU instructions per 64-row tile at 8 queries; here ~650) instead of by the rows it
+// reads and the counts it writes.  Lane l of a tile ends up with row l: the stores are the same coalesced 256 B per array.
+#define RH_SCAN_ROWS_WAVES 4
+template <int NQ>
+__global__ __launch_bounds__(64 * RH_SCAN_ROWS_WAVES) void scan_rows_kernel(const uint4 *__restrict__ fp, uint64_t first, uint64_t count,
+                                                                            const uint32_t *__restrict__ qd /* [NQ][32] */,
+                                                                            const uint32_t *__restrict__ qpop,
+                                                                            uint32_t *__restrict__ and_out, uint32_t *__restrict__ or_out) {
+    __shared__ uint4 s_tr[RH_SCAN_ROWS_WAVES][RH_ROWS_TR_VEC];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t qp[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) qp[i] = qpop[i];
+    const uint64_t n_tiles = (count + 63) / 64;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    uint4 nv[8];
+    uint64_t tile = wave;
+    if (tile < n_tiles) rh_rows_load(fp, first, count, tile, lane, nv);
+    for (; tile < n_tiles; tile += n_waves) {
+        uint4 v[8];
+        rh_rows_turn(nv, s_tr[wv], lane, v);
+        if (tile + n_waves < n_tiles) rh_rows_load(fp, first, count, tile + n_waves, lane, nv);
+        uint32_t rp, a[NQ];
+        rh_rows_count<NQ>(v, qd, rp, a);
+        const uint64_t r = tile * 64 + lane;
+        if (r < count) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                and_out[(uint64_t)i * count + r] = a[i];
+                or_out[(uint64_t)i * count + r] = qp[i] + rp - a[i];
+            }
+        }
+    }
+}
+
 template <int LPR>
 static int launch_scan(radhip_index *idx, int nq, uint64_t first, uint64_t count, const uint4 *dq,
                        const uint32_t *dqpop, uint32_t *da, uint32_t *dorr) {
@@ -714,6 +752,26 @@ static int launch_scan(radhip_index *idx, int nq, uint64_t first, uint64_t count
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, idx->device);
     uint32_t grid = 1;
+    // (RADHIP_SCAN_ROWS=0 keeps the row-across-eight-lanes kernel at every query count: the A/B of profiles/r04)
+    static const bool rows_ok = []() { const char *e = getenv("RADHIP_SCAN_ROWS"); return !(e && e[0] == '0'); }();
+    if (LPR == 8 && nq >= 5 && rows_ok) {
+        const uint64_t groups_r = (count + 64ull * RH_SCAN_ROWS_WAVES - 1) / (64ull * RH_SCAN_ROWS_WAVES);
+#define RH_SCAN_ROWS_CASE(NQV)                                                                  \
+    case NQV: {                                                                                 \
+        int nb = 0;                                                                             \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_rows_kernel<NQV>, 64 * RH_SCAN_ROWS_WAVES, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; } \
+        grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(groups_r, (uint64_t)n_cu * (uint64_t)nb)); \
+        hipLaunchKernelGGL((scan_rows_kernel<NQV>), dim3(grid), dim3(64 * RH_SCAN_ROWS_WAVES), 0, idx->stream, idx->d_fp, \
+                           first, count, reinterpret_cast<const uint32_t *>(dq), dqpop, da, dorr); \
+        break; }
+        switch (nq) {
+            RH_SCAN_ROWS_CASE(5) RH_SCAN_ROWS_CASE(6) RH_SCAN_ROWS_CASE(7) RH_SCAN_ROWS_CASE(8)
+            default: RH_FAIL(RADHIP_E_INVALID, "internal: nq per pass must be 1..8");
+        }
+#undef RH_SCAN_ROWS_CASE
+        RH_HIP(hipGetLastError());
+        return RADHIP_OK;
+    }
 #define RH_SCAN_CASE(NQV)                                                                       \
     case NQV: {                                                                                 \
         int nb = 0;                                                                             \

@@ -7,6 +7,7 @@
 // order of a brute-force scan, which is what tests/test_gpu_kernels.py compares it with.
 // replaces: usearch exact search (`Index.search(..., exact=True)`), used for recall figures only.
 #include "common.h"
+#include "rows_tile.h"
 
 #include <algorithm>
 #include <vector>
@@ -159,21 +160,11 @@ __global__ __launch_bounds__(256) TK_OCC_ATTR void topk_scan_kernel(const uint4 
     }
 }
 
-// 1024-bit rows, ONE ROW PER LANE (round 4).  The kernel above is bound by its instruction stream, not by the memory (1200
-// instructions per tile of 64 rows x 8 queries = 3.0 ms of VALU issue for a 100M-row pass that HBM serves in 2.3 ms): a row lies
-// across eight lanes, so every count goes through a transpose-and-sum (252 instructions per tile) and every lane keeps its own
-// chunk of the eight queries in registers.  Here a wavefront loads its tile with the same coalesced 16-B-per-lane loads, turns it
-// over through LDS (rows 144 B apart: the 16-B reads of 16 lanes cover all 64 banks) and each lane counts a whole row — the
-// queries are the same for every lane, so they are scalar operands (s_load), and nothing crosses lanes.  The next tile's loads
-// are in flight while this one is counted.
-// popcount(x) + acc in ONE instruction (the compiler prefers trees of v_add3 over the accumulating form)
-__device__ __forceinline__ uint32_t tk_bcnt_acc(uint32_t x, uint32_t acc) {
-    uint32_t d;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
-    return d;
-}
-typedef const uint32_t __attribute__((address_space(4))) *tk_cptr;
-#define TK_TR_VEC (32 * 9)       // uint4 per wavefront: 32 rows (half a tile) of 8 chunks + 1 of padding
+// 1024-bit rows, ONE ROW PER LANE (round 4; the tile machinery is rows_tile.h's rh_rows_*).  The kernel above is bound by its
+// instruction stream, not by the memory: 1055 VALU instructions per tile of 64 rows x 8 queries = 3.0 ms of issue for a 100M-row
+// pass that HBM serves in 2.3 ms.  Here: 731 per tile, three wavefronts per SIMD, the next tile's loads in flight while this
+// one is counted (profiles/r04/README.md section 10).
+#define TK_TR_VEC RH_ROWS_TR_VEC
 #define TK_ROWS_WAVES 2          // wavefronts per block: 2 x (candidate buffers + 9 KB tile) stays under 64 KB of dynamic LDS for every k
 template <int NQ>
 __global__ __launch_bounds__(64 * TK_ROWS_WAVES) void topk_rows_kernel(const uint4 *__restrict__ fp, uint64_t first, uint64_t count,
@@ -181,7 +172,6 @@ __global__ __launch_bounds__(64 * TK_ROWS_WAVES) void topk_rows_kernel(const uin
                                                         uint32_t k, uint32_t C, unsigned long long *__restrict__ cand) {
     extern __shared__ unsigned long long tk_smem[];   // [TK_ROWS_WAVES wavefronts][NQ][C] keys, then [TK_ROWS_WAVES][TK_TR_VEC] uint4
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t chunk = lane & 7u, grp = lane >> 3;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned long long *buf = tk_smem + (size_t)wv * NQ * C;
     uint4 *tr = reinterpret_cast<uint4 *>(tk_smem + (size_t)TK_ROWS_WAVES * NQ * C) + (size_t)wv * TK_TR_VEC;
@@ -193,62 +183,14 @@ __global__ __launch_bounds__(64 * TK_ROWS_WAVES) void topk_rows_kernel(const uin
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     uint4 nv[8];
-    auto load_tile = [&](uint64_t tile) {
-        const uint64_t r0 = tile * 64;
-        if (r0 + 64 <= count) {   // (wave-uniform: every tile but the last)
-            const uint4 *base = fp + (first + r0 + grp) * 8 + chunk;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) nv[u] = base[u * 64];
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint64_t r = r0 + (uint64_t)u * 8 + grp;
-                nv[u] = make_uint4(0, 0, 0, 0);
-                if (r < count) nv[u] = fp[(first + r) * 8 + chunk];
-            }
-        }
-    };
     uint64_t tile = wave;
-    if (tile < n_tiles) load_tile(tile);
+    if (tile < n_tiles) rh_rows_load(fp, first, count, tile, lane, nv);
     for (; tile < n_tiles; tile += n_waves) {
-        // the tile is turned over in two halves of 32 rows (4.6 KB of LDS per wavefront instead of 9.2: three wavefronts per SIMD
-        // fit beside the candidate buffers): rows 0..31 go to lanes 0..31, rows 32..63 to lanes 32..63
         uint4 v[8];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) tr[(u * 8 + grp) * 9 + chunk] = nv[h * 4 + u];
-            RH_WAVE_SYNC();
-            if ((int)(lane >> 5) == h) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = tr[(lane & 31u) * 9 + c];
-            }
-            RH_WAVE_SYNC();   // (the half tile is written again right away)
-        }
-        if (tile + n_waves < n_tiles) load_tile(tile + n_waves);
-        uint32_t rp = 0, a[NQ];
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) a[i] = 0;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) rp = tk_bcnt_acc(v[c].x, tk_bcnt_acc(v[c].y, tk_bcnt_acc(v[c].z, tk_bcnt_acc(v[c].w, rp))));
-#pragma unroll
-        for (int cb = 0; cb < 8; cb += 4) {
-            // the same address in every lane: scalar loads from the constant address space (64 B = four chunks of a query at a
-            // time) — behind an offset the compiler cannot see through (0, made wave-uniform again), or it keeps all 256 query
-            // words of the pass in scalar registers across the tile loop and spills them into lanes (314 v_readlane per tile)
-            uint32_t off = 0;
-            asm volatile("" : "+v"(off));
-            const tk_cptr qc = (tk_cptr)(uintptr_t)qd + __builtin_amdgcn_readfirstlane(off) + cb * 4;
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const tk_cptr q = qc + i * 32;
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const uint4 &x = v[cb + cc];
-                    a[i] = tk_bcnt_acc(x.x & q[cc * 4], tk_bcnt_acc(x.y & q[cc * 4 + 1], tk_bcnt_acc(x.z & q[cc * 4 + 2], tk_bcnt_acc(x.w & q[cc * 4 + 3], a[i]))));
-                }
-            }
-        }
+        rh_rows_turn(nv, tr, lane, v);
+        if (tile + n_waves < n_tiles) rh_rows_load(fp, first, count, tile + n_waves, lane, nv);
+        uint32_t rp, a[NQ];
+        rh_rows_count<NQ>(v, qd, rp, a);
         const uint64_t r = tile * 64 + lane;
         tk_offer<NQ>(buf, C, k, lane, lt_mask, r < count, (uint32_t)(first + r), rp, a, qp, cnt, thr);
     }

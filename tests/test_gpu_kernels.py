@@ -37,7 +37,7 @@ def test_synth_graph_matches_oracle(gpu, oracle, n, M, cap0):
 
 
 @pytest.mark.parametrize("ndim", [64, 256, 1024, 2048, 1000])
-@pytest.mark.parametrize("nq", [1, 3, 8, 11])
+@pytest.mark.parametrize("nq", [1, 3, 5, 6, 7, 8, 11])
 def test_scan_matches_oracle(gpu, oracle, ndim, nq):
     rng = np.random.default_rng(ndim + nq)
     n = 3001

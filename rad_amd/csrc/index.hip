@@ -706,16 +706,16 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint4 *__restrict__ fp,
     }
 }
 
-// K1 on 1024-bit rows with ONE ROW PER LANE (rows_tile.h rh_rows_*): used from 5 queries per pass on, where the kernel above is
+// K1 on 1024- and 2048-bit rows with ONE ROW PER LANE (rows_tile.h rh_rows_*): used from 5 queries per pass on, where the kernel above is
 // bound by its instruction stream (1090 VALU instructions per 64-row tile at 8 queries; here ~650) instead of by the rows it
 // reads and the counts it writes.  Lane l of a tile ends up with row l: the stores are the same coalesced 256 B per array.
 #define RH_SCAN_ROWS_WAVES 4
-template <int NQ>
+template <int LPR, int NQ>
 __global__ __launch_bounds__(64 * RH_SCAN_ROWS_WAVES) void scan_rows_kernel(const uint4 *__restrict__ fp, uint64_t first, uint64_t count,
-                                                                            const uint32_t *__restrict__ qd /* [NQ][32] */,
+                                                                            const uint32_t *__restrict__ qd /* [NQ][4 * LPR] */,
                                                                             const uint32_t *__restrict__ qpop,
                                                                             uint32_t *__restrict__ and_out, uint32_t *__restrict__ or_out) {
-    __shared__ uint4 s_tr[RH_SCAN_ROWS_WAVES][RH_ROWS_TR_VEC];
+    __shared__ uint4 s_tr[RH_SCAN_ROWS_WAVES][RH_ROWS_TR_VEC(LPR)];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     uint32_t qp[NQ];
 #pragma unroll
@@ -723,15 +723,15 @@ __global__ __launch_bounds__(64 * RH_SCAN_ROWS_WAVES) void scan_rows_kernel(cons
     const uint64_t n_tiles = (count + 63) / 64;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    uint4 nv[8];
+    uint4 nv[LPR];
     uint64_t tile = wave;
-    if (tile < n_tiles) rh_rows_load(fp, first, count, tile, lane, nv);
+    if (tile < n_tiles) rh_rows_load<LPR>(fp, first, count, tile, lane, nv);
     for (; tile < n_tiles; tile += n_waves) {
-        uint4 v[8];
-        rh_rows_turn(nv, s_tr[wv], lane, v);
-        if (tile + n_waves < n_tiles) rh_rows_load(fp, first, count, tile + n_waves, lane, nv);
+        uint4 v[LPR];
+        rh_rows_turn<LPR>(nv, s_tr[wv], lane, v);
+        if (tile + n_waves < n_tiles) rh_rows_load<LPR>(fp, first, count, tile + n_waves, lane, nv);
         uint32_t rp, a[NQ];
-        rh_rows_count<NQ>(v, qd, rp, a);
+        rh_rows_count<LPR, NQ>(v, qd, rp, a);
         const uint64_t r = tile * 64 + lane;
         if (r < count) {
 #pragma unroll
@@ -754,14 +754,15 @@ static int launch_scan(radhip_index *idx, int nq, uint64_t first, uint64_t count
     uint32_t grid = 1;
     // (RADHIP_SCAN_ROWS=0 keeps the row-across-eight-lanes kernel at every query count: the A/B of profiles/r04)
     static const bool rows_ok = []() { const char *e = getenv("RADHIP_SCAN_ROWS"); return !(e && e[0] == '0'); }();
-    if (LPR == 8 && nq >= 5 && rows_ok) {
+    if ((LPR == 8 || LPR == 16) && nq >= 5 && rows_ok) {
+        constexpr int RL = (LPR == 8 || LPR == 16) ? LPR : 8;   // (the instantiation the other widths never launch)
         const uint64_t groups_r = (count + 64ull * RH_SCAN_ROWS_WAVES - 1) / (64ull * RH_SCAN_ROWS_WAVES);
 #define RH_SCAN_ROWS_CASE(NQV)                                                                  \
     case NQV: {                                                                                 \
         int nb = 0;                                                                             \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_rows_kernel<NQV>, 64 * RH_SCAN_ROWS_WAVES, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; } \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_rows_kernel<RL, NQV>, 64 * RH_SCAN_ROWS_WAVES, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; } \
         grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(groups_r, (uint64_t)n_cu * (uint64_t)nb)); \
-        hipLaunchKernelGGL((scan_rows_kernel<NQV>), dim3(grid), dim3(64 * RH_SCAN_ROWS_WAVES), 0, idx->stream, idx->d_fp, \
+        hipLaunchKernelGGL((scan_rows_kernel<RL, NQV>), dim3(grid), dim3(64 * RH_SCAN_ROWS_WAVES), 0, idx->stream, idx->d_fp, \
                            first, count, reinterpret_cast<const uint32_t *>(dq), dqpop, da, dorr); \
         break; }
         switch (nq) {

@@ -164,17 +164,16 @@ __global__ __launch_bounds__(256) TK_OCC_ATTR void topk_scan_kernel(const uint4 
 // instruction stream, not by the memory: 1055 VALU instructions per tile of 64 rows x 8 queries = 3.0 ms of issue for a 100M-row
 // pass that HBM serves in 2.3 ms.  Here: 731 per tile, three wavefronts per SIMD, the next tile's loads in flight while this
 // one is counted (profiles/r04/README.md section 10).
-#define TK_TR_VEC RH_ROWS_TR_VEC
 #define TK_ROWS_WAVES 2          // wavefronts per block: 2 x (candidate buffers + 9 KB tile) stays under 64 KB of dynamic LDS for every k
-template <int NQ>
+template <int LPR, int NQ>
 __global__ __launch_bounds__(64 * TK_ROWS_WAVES) void topk_rows_kernel(const uint4 *__restrict__ fp, uint64_t first, uint64_t count,
-                                                        const uint32_t *__restrict__ qd /* [NQ][32] */, const uint32_t *__restrict__ qpop,
+                                                        const uint32_t *__restrict__ qd /* [NQ][4 * LPR] */, const uint32_t *__restrict__ qpop,
                                                         uint32_t k, uint32_t C, unsigned long long *__restrict__ cand) {
-    extern __shared__ unsigned long long tk_smem[];   // [TK_ROWS_WAVES wavefronts][NQ][C] keys, then [TK_ROWS_WAVES][TK_TR_VEC] uint4
+    extern __shared__ unsigned long long tk_smem[];   // [TK_ROWS_WAVES wavefronts][NQ][C] keys, then [TK_ROWS_WAVES][RH_ROWS_TR_VEC(LPR)] uint4
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned long long *buf = tk_smem + (size_t)wv * NQ * C;
-    uint4 *tr = reinterpret_cast<uint4 *>(tk_smem + (size_t)TK_ROWS_WAVES * NQ * C) + (size_t)wv * TK_TR_VEC;
+    uint4 *tr = reinterpret_cast<uint4 *>(tk_smem + (size_t)TK_ROWS_WAVES * NQ * C) + (size_t)wv * RH_ROWS_TR_VEC(LPR);
     uint32_t qp[NQ], cnt[NQ];
     unsigned long long thr[NQ];
 #pragma unroll
@@ -182,15 +181,15 @@ __global__ __launch_bounds__(64 * TK_ROWS_WAVES) void topk_rows_kernel(const uin
     const uint64_t n_tiles = (count + 63) / 64;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    uint4 nv[8];
+    uint4 nv[LPR];
     uint64_t tile = wave;
-    if (tile < n_tiles) rh_rows_load(fp, first, count, tile, lane, nv);
+    if (tile < n_tiles) rh_rows_load<LPR>(fp, first, count, tile, lane, nv);
     for (; tile < n_tiles; tile += n_waves) {
-        uint4 v[8];
-        rh_rows_turn(nv, tr, lane, v);
-        if (tile + n_waves < n_tiles) rh_rows_load(fp, first, count, tile + n_waves, lane, nv);
+        uint4 v[LPR];
+        rh_rows_turn<LPR>(nv, tr, lane, v);
+        if (tile + n_waves < n_tiles) rh_rows_load<LPR>(fp, first, count, tile + n_waves, lane, nv);
         uint32_t rp, a[NQ];
-        rh_rows_count<NQ>(v, qd, rp, a);
+        rh_rows_count<LPR, NQ>(v, qd, rp, a);
         const uint64_t r = tile * 64 + lane;
         tk_offer<NQ>(buf, C, k, lane, lt_mask, r < count, (uint32_t)(first + r), rp, a, qp, cnt, thr);
     }
@@ -268,18 +267,19 @@ static int tk_run_pass(radhip_index *idx, int nqp, uint64_t first, uint64_t coun
                        uint32_t *dorr, uint32_t *dc) {
     size_t lds_scan = (size_t)4 * nqp * C * 8;
     uint32_t grid = grid_cap, waves_per_block = 4;
-    // 1024-bit rows: one row per lane (topk_rows_kernel; RADHIP_TOPK_ROWS=0 keeps the row-across-eight-lanes kernel: the A/B of
+    // 1024- and 2048-bit rows: one row per lane (topk_rows_kernel; RADHIP_TOPK_ROWS=0 keeps the row-across-eight-lanes kernel: the A/B of
     // profiles/r04)
     static const bool rows_ok = []() { const char *e = getenv("RADHIP_TOPK_ROWS"); return !(e && e[0] == '0'); }();
-    const bool rows = LPR == 8 && rows_ok;
-    if (rows) { waves_per_block = TK_ROWS_WAVES; lds_scan = (size_t)TK_ROWS_WAVES * ((size_t)nqp * C * 8 + (size_t)TK_TR_VEC * 16); }
+    constexpr int RL = (LPR == 8 || LPR == 16) ? LPR : 8;   // (the instantiation the other widths never launch)
+    const bool rows = (LPR == 8 || LPR == 16) && rows_ok;
+    if (rows) { waves_per_block = TK_ROWS_WAVES; lds_scan = (size_t)TK_ROWS_WAVES * ((size_t)nqp * C * 8 + (size_t)RH_ROWS_TR_VEC(RL) * 16); }
 #define TK_CASE(NQV)                                                                                   \
     case NQV:                                                                                          \
         if (rows) {                                                                                    \
             int nb = 0;                                                                                \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, topk_rows_kernel<NQV>, 64 * TK_ROWS_WAVES, lds_scan) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; } \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, topk_rows_kernel<RL, NQV>, 64 * TK_ROWS_WAVES, lds_scan) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; } \
             grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid_cap, (uint64_t)n_cu * (uint64_t)nb)); \
-            hipLaunchKernelGGL((topk_rows_kernel<NQV>), dim3(grid), dim3(64 * TK_ROWS_WAVES), lds_scan, idx->stream,  \
+            hipLaunchKernelGGL((topk_rows_kernel<RL, NQV>), dim3(grid), dim3(64 * TK_ROWS_WAVES), lds_scan, idx->stream,  \
                                idx->d_fp, first, count, reinterpret_cast<const uint32_t *>(dq), dpop, k, C, dcand); \
             break;                                                                                     \
         }                                                                                              \

@@ -18,6 +18,7 @@
 #include <new>
 
 #define BK_INF 0xFFFFFFFFFFFFFFFFull
+#define BK_REG_EF_CAP 512u   // up to this many entries the sorted top buffer of a search lives in registers (8 per lane)
 #define VIS_EMPTY 0xFFFFFFFFu
 
 __host__ __device__ __forceinline__ unsigned long long bk_key(uint32_t q24, uint32_t slot) {
@@ -33,22 +34,9 @@ __device__ __forceinline__ uint32_t bk_q(unsigned long long k) { return (uint32_
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
     } while (0)
 
-__device__ __forceinline__ unsigned long long bk_wave_min_u64(unsigned long long v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        unsigned long long o = __shfl_xor(v, m, RH_WAVE);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-__device__ __forceinline__ uint32_t bk_wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        uint32_t o = __shfl_xor(v, m, RH_WAVE);
-        v = o < v ? o : v;
-    }
-    return v;
-}
+// wave-wide minima by DPP (common.h): the shuffle forms went through LDS (ds_bpermute) six times per call
+__device__ __forceinline__ unsigned long long bk_wave_min_u64(unsigned long long v) { return rh_wave_min_u64(v); }
+__device__ __forceinline__ uint32_t bk_wave_min_u32(uint32_t v) { return rh_wave_min_u32(v); }
 
 struct GraphView {
     const uint4 *fp;
@@ -77,8 +65,10 @@ struct WaveLds {
 
 __device__ __forceinline__ WaveLds carve_lds(unsigned char *base, uint32_t ef_cap) {
     WaveLds L;
+    // one buffer of ef_cap keys when the search keeps its top buffer in registers (ef_cap <= 512: search_layer_reg moves the
+    // entries through it between merges), two (ping-pong) for search_layer
     L.topA = reinterpret_cast<unsigned long long *>(base);
-    L.topB = L.topA + ef_cap;
+    L.topB = ef_cap <= BK_REG_EF_CAP ? L.topA : L.topA + ef_cap;
     L.newk = L.topB + ef_cap;
     L.u32a = reinterpret_cast<uint32_t *>(L.newk + 128);
     L.u32b = L.u32a + 64;
@@ -86,7 +76,7 @@ __device__ __forceinline__ WaveLds carve_lds(unsigned char *base, uint32_t ef_ca
     L.claim = L.u32c + 64;
     return L;
 }
-static size_t wave_lds_bytes(uint32_t ef_cap) { return (size_t)ef_cap * 16 + 128 * 8 + 3 * 64 * 4 + 128 * 4; }
+static size_t wave_lds_bytes(uint32_t ef_cap) { return (size_t)ef_cap * (ef_cap <= BK_REG_EF_CAP ? 8 : 16) + 128 * 8 + 3 * 64 * 4 + 128 * 4; }
 
 // Tanimoto of the wave's query chunk `qv` against up to 64 rows whose slots are in
 // L.u32a[0..n); results (and, or) to L.u32b / L.u32c.
@@ -118,6 +108,14 @@ __device__ __forceinline__ bool vis_test_and_set(uint32_t *vis, uint32_t vmask, 
 }
 
 struct SearchCounters { uint64_t evals, pops; int32_t status; };
+// -DBK_PROFILE: where a search spends its time (s_memtime ticks per section of search_layer_reg, summed over all wavefronts and
+// printed by radhip_index_link_resident): the build's counterpart of traverse4.inc's RH_PROFILE
+#ifdef BK_PROFILE
+__device__ unsigned long long bk_prof[8];
+#define BK_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define BK_T(i) do { } while (0)
+#endif
 
 // best-first search on one level.  In: sorted top (topA) with n_top entries whose slots are
 // already in `vis`.  Out: sorted top in L.topA (buffers swapped back), returns n_top.
@@ -229,6 +227,156 @@ __device__ uint32_t search_layer(const GraphView &G, const uint4 qv, uint32_t qp
     return n_top;
 }
 
+// ---- the same search with the sorted top buffer IN REGISTERS (round 4) ------------------------------------------------------
+// Counters of the 100M-row build at expansion_add 400 (profiles/r04/README.md section 11): a pop takes 6.5 us of which 42 % are
+// the scan for the first unexpanded entry and the merge of the new keys — chains of dependent LDS reads (a binary search per
+// old entry, per new key).  Here entry i of the buffer lives in lane i % 64, register i / 64 (EPL registers: ef <= 64 * EPL):
+// the scan is a compare per register and one DPP minimum; the merge counts, per new key (a scalar broadcast from the lane
+// that holds it), the old entries below it with a ballot per register and bumps the shift of those above it — no search at
+// all; the entries then move to their new lanes through ONE LDS buffer (independent writes and reads).  Same order of pops,
+// same buffer contents at every step as search_layer (tests: adjacency bit-exact against the oracle).
+__device__ __forceinline__ unsigned long long bk_readlane64(unsigned long long v, uint32_t ln) {   // ln wave-uniform
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)ln) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)ln);
+}
+template <int EPL>
+__device__ __forceinline__ unsigned long long bk_top_get(const unsigned long long (&t)[EPL], uint32_t pos) {   // pos wave-uniform
+    unsigned long long v = BK_INF;
+    const uint32_t kk = pos >> 6, ln = pos & 63u;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k)
+        if ((uint32_t)k == kk) v = bk_readlane64(t[k], ln);
+    return v;
+}
+
+template <int LPR, int EPL>
+__device__ uint32_t search_layer_reg(const GraphView &G, const uint4 qv, uint32_t qpop, uint32_t level, uint32_t ef,
+                                     uint32_t n_top, WaveLds &L, uint32_t *vis, uint32_t vlog2, uint32_t &vis_count,
+                                     SearchCounters &C, uint32_t lane) {
+    const uint32_t vmask = (1u << vlog2) - 1u, vshift = 32u - vlog2;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned long long t[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) { const uint32_t i = 64u * k + lane; t[k] = i < n_top ? L.topA[i] : BK_INF; }
+#ifdef BK_PROFILE
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    struct Flush { unsigned long long *p; uint32_t lane; __device__ ~Flush() { if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&bk_prof[i], p[i]); } } flush_{pacc, lane};
+#endif
+    for (;;) {
+        BK_T(0);
+        uint32_t first = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = EPL - 1; k >= 0; --k)
+            if (!(t[k] & 1ull)) first = 64u * k + lane;      // (BK_INF reads as expanded)
+        const uint32_t pos = rh_wave_min_u32(first);
+        if (pos == 0xFFFFFFFFu) break;
+        const unsigned long long ck = bk_top_get<EPL>(t, pos);
+#pragma unroll
+        for (int k = 0; k < EPL; ++k)
+            if ((uint32_t)k == (pos >> 6) && lane == (pos & 63u)) t[k] |= 1ull;
+        BK_T(1);
+        C.pops++;
+        const uint32_t cur = bk_slot(ck);
+        uint32_t cap;
+        const uint32_t *row = gv_row(G, cur, level, &cap);
+        uint32_t nb = RADHIP_NO_SLOT;
+        if (lane < cap) nb = row[lane];
+        bool isnew = false;
+        {   // visited test-and-set (see search_layer)
+            bool pending = nb != RADHIP_NO_SLOT, cand = false;
+            uint32_t h = (nb * 2654435769u) >> vshift, ci = 0;
+            for (;;) {
+                if (pending) {
+                    for (;;) {
+                        const uint32_t e = __hip_atomic_load(&vis[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (e == VIS_EMPTY) { cand = true; break; }
+                        if (e == nb) break;
+                        h = (h + 1u) & vmask;
+                    }
+                    pending = false;
+                }
+                if (cand) {
+                    cand = false;
+                    if (claim_bucket<128u>(L.claim, h, ci)) {
+                        isnew = true;
+                        __hip_atomic_store(&vis[h], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else { pending = true; h = (h + 1u) & vmask; }
+                }
+                if (!__ballot(pending)) break;
+            }
+            if (isnew) L.claim[ci] = 0u;
+        }
+        const unsigned long long nbal = __ballot(isnew);
+        const uint32_t nn = (uint32_t)__popcll(nbal);
+        BK_T(2);
+        if (nn == 0) continue;
+        vis_count += nn;
+        if (vis_count > (1u << vlog2) / 2u) { C.status = RADHIP_E_CAPACITY; break; }
+        const uint32_t rank = (uint32_t)__popcll(nbal & lt_mask);
+        if (isnew) L.u32a[rank] = nb;
+        WSYNC();
+        eval_rows<LPR>(G.fp, qv, qpop, L, nn, lane);
+        C.evals += nn;
+        BK_T(3);
+        unsigned long long key = BK_INF;
+        if (lane < nn) key = bk_key(rh_q24_dev(L.u32b[lane], L.u32c[lane]), L.u32a[lane]);
+        bool keep = lane < nn;
+        if (n_top == ef) keep = keep && ((key >> 1) < (bk_top_get<EPL>(t, ef - 1u) >> 1));
+        const unsigned long long kb = __ballot(keep);
+        const uint32_t m = (uint32_t)__popcll(kb);
+#ifdef BK_PROFILE
+        pacc[6] += 1; pacc[7] += m;
+#endif
+        BK_T(4);
+        if (m == 0) continue;
+        // rank of every kept key among the kept keys, without LDS: the kept lanes' keys pass by as scalars
+        uint32_t r_new = 0;
+        for (unsigned long long rest = kb; rest; rest &= rest - 1ull) {
+            const unsigned long long ko = bk_readlane64(key, (uint32_t)__builtin_ctzll(rest));
+            r_new += (keep && ko < key) ? 1u : 0u;
+        }
+        uint32_t shift[EPL];
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) shift[k] = 0;
+        for (uint32_t j = 0; j < m; ++j) {
+            const unsigned long long kj = bk_readlane64(key, (uint32_t)__builtin_ctzll(__ballot(keep && r_new == j)));   // the j-th new key
+            uint32_t lo = 0;
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) {
+                lo += (uint32_t)__popcll(__ballot((t[k] >> 1) < (kj >> 1)));      // old entries below the new key (BK_INF never is)
+                shift[k] += ((kj >> 1) < (t[k] >> 1)) ? 1u : 0u;                  // ... and the old entries it pushes up
+            }
+            const uint32_t p = j + lo;
+            if (lane == 0 && p < ef) L.topB[p] = kj;
+        }
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const uint32_t i = 64u * k + lane, p = i + shift[k];
+            if (i < n_top && p < ef) L.topB[p] = t[k];
+        }
+        n_top = n_top + m < ef ? n_top + m : ef;
+        WSYNC();
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) { const uint32_t i = 64u * k + lane; t[k] = i < n_top ? L.topB[i] : BK_INF; }
+        BK_T(5);
+    }
+    WSYNC();
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) { const uint32_t i = 64u * k + lane; if (i < n_top) L.topA[i] = t[k]; }
+    WSYNC();
+    return n_top;
+}
+
+// the buffer in registers when it fits eight per lane, in LDS beyond (expansion_add > 512)
+template <int LPR>
+__device__ __forceinline__ uint32_t search_layer_any(const GraphView &G, const uint4 qv, uint32_t qpop, uint32_t level, uint32_t ef,
+                                                     uint32_t ef_cap, uint32_t n_top, WaveLds &L, uint32_t *vis, uint32_t vlog2,
+                                                     uint32_t &vis_count, SearchCounters &C, uint32_t lane) {
+    if (ef_cap <= 128u) return search_layer_reg<LPR, 2>(G, qv, qpop, level, ef, n_top, L, vis, vlog2, vis_count, C, lane);
+    if (ef_cap <= BK_REG_EF_CAP) return search_layer_reg<LPR, 8>(G, qv, qpop, level, ef, n_top, L, vis, vlog2, vis_count, C, lane);
+    return search_layer<LPR>(G, qv, qpop, level, ef, n_top, L, vis, vlog2, vis_count, C, lane);
+}
+
 // greedy 1-best move on one level until no neighbour is closer
 template <int LPR>
 __device__ unsigned long long greedy_level(const GraphView &G, const uint4 qv, uint32_t qpop, uint32_t level,
@@ -335,7 +483,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchParams P) {
     uint32_t vis_count = 1;
     if (lane == 0) { vis_test_and_set(vis, (1u << P.vlog2) - 1u, 32u - P.vlog2, bk_slot(curk)); L.topA[0] = curk; }
     WSYNC();
-    uint32_t n_top = search_layer<LPR>(P.G, qv, qpop, 0, P.ef, 1, L, vis, P.vlog2, vis_count, C, lane);
+    uint32_t n_top = search_layer_any<LPR>(P.G, qv, qpop, 0, P.ef, P.ef_cap, 1, L, vis, P.vlog2, vis_count, C, lane);
     const uint32_t nk = n_top < P.k ? n_top : P.k;
     // (and, or) are recomputed for the k results from their slots
     for (uint32_t base = 0; base < nk; base += 64) {
@@ -379,8 +527,15 @@ struct BuildParams {
     int32_t *status;               // [batch_n]
 };
 
+// Six wavefronts per SIMD (80 VGPRs instead of 81) beside 6.4 KB of LDS per wavefront at expansion_add 400: 24 searches per CU
+// instead of 15 — the search is a chain of dependent memory accesses, so the wavefronts in flight are its throughput
+// (10M rows: 9.44 -> 8.84 s; with two LDS buffers and 15 wavefronts per CU 11.2 s; -DBK_WAVES_PER_EU=5 for the A/B).
+#ifndef BK_WAVES_PER_EU
+#define BK_WAVES_PER_EU 6
+#endif
+#define BK_OCC_ATTR __attribute__((amdgpu_waves_per_eu(BK_WAVES_PER_EU, BK_WAVES_PER_EU)))
 template <int LPR>
-__global__ __launch_bounds__(64) void build_insert_kernel(BuildParams P) {
+__global__ __launch_bounds__(64) BK_OCC_ATTR void build_insert_kernel(BuildParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WaveLds L = carve_lds(smem, P.ef_cap);
     const uint32_t lane = threadIdx.x;
@@ -402,7 +557,7 @@ __global__ __launch_bounds__(64) void build_insert_kernel(BuildParams P) {
         uint32_t vis_count = 1;
         if (lane == 0) { vis_test_and_set(vis, (1u << P.vlog2) - 1u, 32u - P.vlog2, bk_slot(curk)); L.topA[0] = curk & ~1ull; }
         WSYNC();
-        const uint32_t n_top = search_layer<LPR>(P.G, qv, qpop, (uint32_t)l, P.ef, 1, L, vis, P.vlog2, vis_count, C, lane);
+        const uint32_t n_top = search_layer_any<LPR>(P.G, qv, qpop, (uint32_t)l, P.ef, P.ef_cap, 1, L, vis, P.vlog2, vis_count, C, lane);
         if (C.status) break;
         uint32_t cap;
         uint32_t *row = gv_row(P.G, i, (uint32_t)l, &cap);
@@ -814,6 +969,17 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
     return add_impl(idx, rows, count, seed, max_batch);
 }
 
+#ifdef BK_PROFILE
+static void bk_prof_print() {
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(bk_prof), sizeof h) != hipSuccess) return;
+    unsigned long long tot = 0; for (int i = 0; i < 6; ++i) tot += h[i];
+    const char *nm[6] = {"loop-top", "scan+mark", "adjacency+probe", "eval", "keys+filter", "merge"};
+    fprintf(stderr, "[bk_prof] %llu ticks:", tot);
+    for (int i = 0; i < 6; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * h[i] / (tot ? tot : 1));
+    fprintf(stderr, "; %llu pops with new neighbours, %.2f kept keys each\n", h[6], h[6] ? (double)h[7] / h[6] : 0.0);
+}
+#endif
 extern "C" int radhip_index_link_resident(radhip_index_t *idx, uint64_t seed, uint32_t max_batch) {
     if (!idx) RH_FAIL(RADHIP_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
@@ -821,7 +987,13 @@ extern "C" int radhip_index_link_resident(radhip_index_t *idx, uint64_t seed, ui
     const uint64_t linked = idx->has_graph ? idx->g_n : 0;
     if (idx->n < linked) RH_FAIL(RADHIP_E_STATE, "the graph has more nodes (%llu) than the corpus has rows (%llu)",
                                  (unsigned long long)linked, (unsigned long long)idx->n);
+#ifdef BK_PROFILE
+    const int rc_ = add_impl(idx, nullptr, idx->n - linked, seed, max_batch);
+    bk_prof_print();
+    return rc_;
+#else
     return add_impl(idx, nullptr, idx->n - linked, seed, max_batch);
+#endif
 }
 
 extern "C" int radhip_search(radhip_index_t *idx, const uint8_t *queries, uint32_t nq, uint32_t k, uint32_t ef,

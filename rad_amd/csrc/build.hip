@@ -111,7 +111,7 @@ struct SearchCounters { uint64_t evals, pops; int32_t status; };
 // -DBK_PROFILE: where a search spends its time (s_memtime ticks per section of search_layer_reg, summed over all wavefronts and
 // printed by radhip_index_link_resident): the build's counterpart of traverse4.inc's RH_PROFILE
 #ifdef BK_PROFILE
-__device__ unsigned long long bk_prof[8];
+__device__ unsigned long long bk_prof[12];   // [0..5] sections of search_layer_reg, [6] pops with new neighbours, [7] kept keys, [8] whole insert, [9] select_heuristic, [10] candidates it examined, [11] calls
 #define BK_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - tlast; tlast = t_; } while (0)
 #else
 #define BK_T(i) do { } while (0)
@@ -437,6 +437,59 @@ __device__ uint32_t select_heuristic(const uint4 *fp, const unsigned long long *
     return k;
 }
 
+// The same selection for rows of at most 2 * (64 / LPR) slots (connectivity 8 at 1024 bits: 16 / 8), without a dependent HBM
+// round trip per candidate (round 4: select_heuristic was 15 % of an insert at expansion_add 400 — 400 candidates, each one
+// load of its fingerprint and a reload of every selected row).  Candidates come in chunks of 64 / LPR rows: one wave-load per
+// chunk (the next chunk's is in flight meanwhile), staged in 1 KB of LDS (`tile`) from which every lane group reads the
+// candidate's row; the selected rows stay in REGISTERS — selected row s in lane group s % RPP, register s / RPP — so a
+// candidate meets all of them in two passes of popcounts and no load.  Same candidates examined in the same order, same
+// comparisons: same selection.
+// (not inlined: inside the kernel its registers cost the search loop spills — 8.92 s inlined, 8.33 s as a call, 10M rows)
+template <int LPR>
+__device__ __attribute__((noinline)) uint32_t select_heuristic_regs(const uint4 *fp, const unsigned long long *cand, uint32_t n, uint32_t cap,
+                                          uint32_t *sel, uint4 *tile, uint32_t lane) {
+    constexpr uint32_t RPP = 64 / LPR;
+    const uint32_t chunk = lane % LPR, grp = lane / LPR;
+    uint4 sv0 = make_uint4(0, 0, 0, 0), sv1 = make_uint4(0, 0, 0, 0);
+    uint32_t sp0 = 0, sp1 = 0, k = 0;
+    auto load = [&](uint32_t base) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (base + grp < n) v = fp[(uint64_t)bk_slot(cand[base + grp]) * LPR + chunk];
+        return v;
+    };
+    uint4 cur = load(0);
+    for (uint32_t base = 0; base < n && k < cap; base += RPP) {
+        const uint4 nxt = base + RPP < n ? load(base + RPP) : make_uint4(0, 0, 0, 0);
+        tile[lane] = cur;
+        WSYNC();
+        for (uint32_t j = 0; j < RPP && base + j < n && k < cap; ++j) {
+            const unsigned long long ck = cand[base + j];
+            const uint32_t c = bk_slot(ck), qc = bk_q(ck);
+            const uint4 cv = tile[j * LPR + chunk];
+            const uint32_t cpop = rh_group_sum<LPR>(rh_popc4(cv));
+            bool bad = false;
+            {
+                const uint32_t aa = rh_group_sum<LPR>(rh_popc4_and(sv0, cv));
+                if (grp < k && rh_q24_dev(aa, sp0 + cpop - aa) < qc) bad = true;
+            }
+            if (k > RPP) {
+                const uint32_t aa = rh_group_sum<LPR>(rh_popc4_and(sv1, cv));
+                if (RPP + grp < k && rh_q24_dev(aa, sp1 + cpop - aa) < qc) bad = true;
+            }
+            if (!__ballot(bad)) {
+                if (lane == 0) sel[k] = c;
+                if (k < RPP) { if (grp == k) { sv0 = cv; sp0 = cpop; } }
+                else if (grp == k - RPP) { sv1 = cv; sp1 = cpop; }
+                k++;
+            }
+        }
+        WSYNC();
+        cur = nxt;
+    }
+    WSYNC();
+    return k;
+}
+
 // ------------------------------------------------------------- search kernel
 struct SearchParams {
     GraphView G;
@@ -539,6 +592,9 @@ __global__ __launch_bounds__(64) BK_OCC_ATTR void build_insert_kernel(BuildParam
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WaveLds L = carve_lds(smem, P.ef_cap);
     const uint32_t lane = threadIdx.x;
+#ifdef BK_PROFILE
+    struct Whole { unsigned long long t0; uint32_t lane; __device__ ~Whole() { if (lane == 0) atomicAdd(&bk_prof[8], __builtin_amdgcn_s_memtime() - t0); } } whole_{__builtin_amdgcn_s_memtime(), lane};
+#endif
     L.claim[lane] = 0u; L.claim[lane + 64u] = 0u;
     const uint32_t i = P.batch_start + blockIdx.x;
     const uint4 qv = P.G.fp[(uint64_t)i * LPR + lane % LPR];
@@ -561,7 +617,15 @@ __global__ __launch_bounds__(64) BK_OCC_ATTR void build_insert_kernel(BuildParam
         if (C.status) break;
         uint32_t cap;
         uint32_t *row = gv_row(P.G, i, (uint32_t)l, &cap);
-        const uint32_t k = select_heuristic<LPR>(P.G.fp, L.topA, n_top, cap, L.u32a, lane);
+#ifdef BK_PROFILE
+        const unsigned long long ts0_ = __builtin_amdgcn_s_memtime();
+#endif
+        const uint32_t k = cap <= 2u * (64u / LPR)
+                               ? select_heuristic_regs<LPR>(P.G.fp, L.topA, n_top, cap, L.u32a, reinterpret_cast<uint4 *>(L.newk), lane)
+                               : select_heuristic<LPR>(P.G.fp, L.topA, n_top, cap, L.u32a, lane);
+#ifdef BK_PROFILE
+        if (lane == 0) { atomicAdd(&bk_prof[9], __builtin_amdgcn_s_memtime() - ts0_); atomicAdd(&bk_prof[10], (unsigned long long)n_top); atomicAdd(&bk_prof[11], 1ull); }
+#endif
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(P.req_count, (unsigned long long)k);
         base = __shfl(base, 0, RH_WAVE);
@@ -971,13 +1035,15 @@ extern "C" int radhip_index_add(radhip_index_t *idx, const uint8_t *rows, uint64
 
 #ifdef BK_PROFILE
 static void bk_prof_print() {
-    unsigned long long h[8];
+    unsigned long long h[12];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(bk_prof), sizeof h) != hipSuccess) return;
     unsigned long long tot = 0; for (int i = 0; i < 6; ++i) tot += h[i];
     const char *nm[6] = {"loop-top", "scan+mark", "adjacency+probe", "eval", "keys+filter", "merge"};
     fprintf(stderr, "[bk_prof] %llu ticks:", tot);
     for (int i = 0; i < 6; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * h[i] / (tot ? tot : 1));
     fprintf(stderr, "; %llu pops with new neighbours, %.2f kept keys each\n", h[6], h[6] ? (double)h[7] / h[6] : 0.0);
+    fprintf(stderr, "[bk_prof] whole inserts %llu ticks: the searches' sections %.1f%%, select_heuristic %.1f%% (%llu calls over %.1f candidates each)\n",
+            h[8], 100.0 * tot / (h[8] ? h[8] : 1), 100.0 * h[9] / (h[8] ? h[8] : 1), h[11], h[11] ? (double)h[10] / h[11] : 0.0);
 }
 #endif
 extern "C" int radhip_index_link_resident(radhip_index_t *idx, uint64_t seed, uint32_t max_batch) {

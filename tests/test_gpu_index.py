@@ -21,7 +21,10 @@ def _rows(oracle, n, ndim, seed):
     (1024, 4000, 8, 16, 64, 256),      # batched
     (64, 1200, 4, 8, 20, 64),          # the reference tests' shape (tests/test_hnsw_service.py:13-28)
     (2048, 1500, 16, 32, 100, 128),
-    (1024, 2500, 8, 16, 400, 512),     # README expansion_add
+    (1024, 2500, 8, 16, 400, 512),     # README expansion_add (the top buffer in registers, eight entries per lane)
+    (1024, 1500, 8, 16, 128, 64),      # ... two per lane
+    (1024, 1800, 8, 16, 600, 256),     # expansion_add > 512: the top buffer in LDS (search_layer), two buffers
+    (2048, 1200, 32, 64, 100, 64),     # rows of 64 slots: the neighbour selection that reloads the selected rows
 ])
 def test_index_add_matches_oracle_builder(gpu, oracle, ndim, n, M, cap0, ef, max_batch):
     from rad_amd.index import Index
@@ -63,7 +66,8 @@ def test_index_add_in_two_calls_matches_oracle(gpu, oracle):
 
 
 @pytest.mark.parametrize("ndim,n,M,ef_add,k,ef", [(1024, 5000, 8, 64, 10, 64), (1024, 5000, 8, 64, 100, 400),
-                                                  (64, 1500, 4, 20, 5, 16), (2048, 3000, 16, 64, 32, 32)])
+                                                  (64, 1500, 4, 20, 5, 16), (2048, 3000, 16, 64, 32, 32),
+                                                  (1024, 4000, 8, 64, 50, 700)])     # expansion > 512: the LDS top buffer
 def test_search_matches_oracle_search(gpu, oracle, ndim, n, M, ef_add, k, ef):
     from rad_amd.index import Index
     X = _rows(oracle, n, ndim, 77)

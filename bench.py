@@ -81,6 +81,8 @@ def parse_args():
                     help="N = 1: a second, shorter leg on a graph built with this expansion_add (0 = skip)")
     ap.add_argument("--graph-cache", default="", help="profiling sessions: .npz the built graph is saved to / loaded from, so that every "
                                                        "rocprofv3 pass does not build it again (the graph is the same; only setup time changes)")
+    ap.add_argument("--build-batch", type=int, default=16384,
+                    help="inserts per batch of the graph build (a batch searches the pre-batch graph; at most 1/16 of the graph so far, at most 65536)")
     ap.add_argument("--chain", type=int, default=20,
                     help="steps (batches) chained into ONE launch of the traversal kernel: a launch ends with its longest traversals running "
                          "alone (~150 ms whatever its size), so the tail is paid once per chain (0 = the two-object pipeline of overlapped launches)")
@@ -196,7 +198,7 @@ def build_index(args, mode, device, layout=True):
         idx.synth_graph(seed=777)
     else:
         cache = getattr(args, "graph_cache", "")
-        cache = f"{cache}.n{n}.m{M}.ef{args.expansion_add}.mode{mode}.npz" if cache else ""
+        cache = f"{cache}.n{n}.m{M}.ef{args.expansion_add}.mode{mode}.b{args.build_batch}.npz" if cache else ""
         if cache and os.path.exists(cache):
             z = np.load(cache)
             idx.load_graph(z["levels"], z["adj0"], z["upper_row"], z["adjU"], int(z["max_level"]), int(z["entry"]))
@@ -206,7 +208,7 @@ def build_index(args, mode, device, layout=True):
             # the rows are resident already (generated on the device): they are linked where they are, no host copy
             # of the corpus (radhip_index_link_resident == radhip_index_add of the same rows, tests/test_gpu_sharded.py)
             t_build = time.perf_counter()
-            idx.link_resident(seed=777, max_batch=16384)
+            idx.link_resident(seed=777, max_batch=args.build_batch)
             t_build = time.perf_counter() - t_build
             note(f"graph built in {t_build:.1f} s")
             if cache:
@@ -800,7 +802,7 @@ def run_sharded_native(args, grp, rank, world, local_rank, barrier):
             full.synth_graph(seed=777)
         else:
             t_build = time.perf_counter()
-            full.link_resident(seed=777, max_batch=16384)      # rows already resident: no host copy of the corpus
+            full.link_resident(seed=777, max_batch=args.build_batch)      # rows already resident: no host copy of the corpus
             t_build = time.perf_counter() - t_build
         peak_full = int(full.info().device_bytes)
         if want_ref:
@@ -1018,7 +1020,7 @@ def main():
                     f"(level-0 width {2 * args.connectivity}), {args.nq} concurrent best-first RAD traversals per GPU to "
                     f"n_to_score={args.n_to_score}, synthetic {corpus_desc}, {graph_desc}",
         "rows": n, "ndim": args.ndim, "connectivity": args.connectivity, "nq_per_gpu": args.nq, "n_to_score": args.n_to_score,
-        "corpus_mode": args.corpus_mode, "expansion_add": args.expansion_add, "graph_build_s": t_build,
+        "corpus_mode": args.corpus_mode, "expansion_add": args.expansion_add, "graph_build_s": t_build, "graph_build_batch": args.build_batch,
         "graph_recall_at_10_ef128": recall, "graph_recall_at_10_ef400": recall400,
         "traversal_state": {"objects": leg["objects"], "rows_with_tables_per_object": leg["slots"] or args.nq, "bytes": leg["state_bytes"],
                             "steps_per_launch": leg.get("chain", 1), "scored_list_ring": leg.get("list_ring", 0),

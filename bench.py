@@ -477,7 +477,7 @@ def config_legs(args, device):
     # configs[1]: 1M 1024-bit fingerprints, connectivity 8, single MI355X (Tanimoto kernels; traversals to 1 % of the corpus like the
     # two legs below — RAD's regime, index.html:628; to 100k = 10 % of this corpus most neighbours of a pop are scored already:
     # 2.2 evaluations per expansion, frac 0.064 in the round's earlier lines)
-    one("c1_1M_1024bit_m8", 1_000_000, 1024, 8, 64, 65536, 10_000)
+    one("c1_1M_1024bit_m8", 1_000_000, 1024, 8, 400, 65536, 10_000)     # (expansion_add as the reference README builds: README.md:52)
     # configs[4]: 2048-bit fingerprints, connectivity 32, expansion_add 400 (2M rows: what builds inside the budget)
     one("c4_2M_2048bit_m32_ef400", 2_000_000, 2048, 32, 400, 16384, 20_000)
     # the reference notebook's shape (examples/DUDEZ_example.ipynb:165-166): connectivity 16, expansion_add 400

@@ -126,3 +126,23 @@ def test_bench_four_ranks_on_one_device(gpu):
     done, total = pm["parity_vs_whole_corpus_index"].split("/")
     assert done == total and int(total) >= 4 * 256 and pm["remote_share_of_row_reads"] == 0.75
     assert len(pm["index_bytes_per_rank"]) == 4
+
+
+def test_bench_under_the_drivers_launcher(gpu):
+    """the driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N ...`: bench.py takes RANK / WORLD_SIZE / MASTER_* from that environment (its own TCP star on MASTER_PORT + 1;
+    torch itself is never imported by bench.py) and rank 0 prints the one line."""
+    pytest.importorskip("torch")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--rows", "300000", "--nq", "512", "--n-to-score", "1500", "--sharded-nq", "64", "--exchange", "host",
+                          "--single-device"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    _contract(j, 2, 2)
+    assert j["value"] == j["replicas"]["value"] > 0
+    done, total = j["sharded"]["parity_vs_single_gpu"].split("/")
+    assert done == total and int(total) >= 2 * 64
+    assert j["peer_mapped"].get("error") is None
